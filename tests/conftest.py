@@ -1,0 +1,40 @@
+"""pytest configuration: markers, repo root on sys.path, fixture loaders shared by the suite."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NOISE_KIND = dict(WHITE_NOISE=1, GAUSSIAN_MIXTURE=2, GAUSSIAN_BIMODAL=3, ALPHA_STABLE=4, UNIFORM=5)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + '*.npz')))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    d = {k: z[k] for k in z.files}
+    d['meta'] = json.loads(str(d['meta']))
+    return d
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.fixture(scope='session')
+def root():
+    return ROOT

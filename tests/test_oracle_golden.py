@@ -1,0 +1,113 @@
+"""The oracle is pinned to the reference: every restatement under oracle/ must reproduce the
+golden vectors that oracle/gen_golden.py captured from the unmodified reference
+(experiment.py Experiment.run, noise.py NoiseProfiler.getNoise) in the build container."""
+import numpy as np
+import pytest
+
+from conftest import NOISE_KIND, golden_names, load_golden, rel_err
+from oracle import noise_ref, plant_ref, rmckf_block, rmckf_dense
+
+CLOSED = golden_names('closed_')
+NOISE = golden_names('noise_')
+# closed loops whose feedback amplifies rounding differences (1e-15 -> O(1) within the run):
+CHAOTIC = {'closed_gmckf_mix_anneal_hold'}
+
+
+def _noise_stream(meta, m=8):
+    return noise_ref.NoiseStreamRef(m, NOISE_KIND[meta['noise_type']], meta['seed'], meta['hold'], meta['hold_cnt'],
+                                    **meta['noise_params'])
+
+
+def test_fixture_inventory():
+    assert len(NOISE) >= 16 and len(CLOSED) >= 17
+
+
+@pytest.mark.parametrize('name', NOISE)
+def test_noise_restatement_bit_exact(name):
+    g = load_golden(name)
+    got = _noise_stream(g['meta'], g['meta']['m']).take(len(g['values']))
+    assert np.array_equal(got, g['values'])
+
+
+def test_noise_known_answers_survey_appendix_b():
+    g = load_golden('noise_alpha1p5')
+    assert g['values'][0, 0] == 0.6341795339174561 and g['values'][1, 0] == -1.1841354142340323
+    j = load_golden('noise_uniform_jitter')['values'][0]
+    assert j[0] == 0.22733602246716966 and j[1] == 0.6711037852493347
+
+
+def test_noise_seed_aliasing():
+    """trial s feature i+1 == trial s+10 feature i (noise.py:70 + main.py:139)."""
+    a = noise_ref.NoiseStreamRef(8, noise_ref.ALPHA_STABLE, 500, alpha=1.5, beta=0, gamma=1, delta=0).take(20)
+    b = noise_ref.NoiseStreamRef(8, noise_ref.ALPHA_STABLE, 510, alpha=1.5, beta=0, gamma=1, delta=0).take(20)
+    assert np.array_equal(a[:, 1:], b[:, :-1])
+
+
+@pytest.mark.parametrize('name', CLOSED)
+def test_dense_restatement_reproduces_reference(name):
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    out = rmckf_dense.run_closed_loop(
+        plant_ref.PinholeUR10(meta['dt']), g['q_start'], g['desired'], _noise_stream(meta).next, meta['dt'], meta['t_max'],
+        meta['gain'], method=meta['method'], initial_guess=p['initial_guess'], kernel_bw=p['kernel_bw'],
+        annealing=p['annealing'], fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'], capture=True)
+    assert out['status'] == int(g['status']) and out['k_done'] == len(g['t']) == 299
+    assert np.array_equal(out['t'], g['t']) and np.array_equal(out['noise'], g['noise'])
+    # same numpy/LAPACK build => same bits; tolerance leaves room for a different BLAS on the GPU box
+    tol = 1e-6 if name in CHAOTIC else 1e-11
+    for key, ref in (('err', g['err']), ('q', g['q']), ('f', g['f'])):
+        assert rel_err(out[key], ref) <= tol, key
+    assert rel_err(out['X'][g['X_steps']], g['X']) <= tol
+    assert rel_err(out['Pblk'][g['P_steps']], g['P_blocks']) <= tol
+    assert float(g['P_offblock_max']) == 0.0                      # P is exactly block diagonal
+    assert np.array_equal(out['dq'][:-1], g['dq_prev'][1:]) or rel_err(out['dq'][:-1], g['dq_prev'][1:]) <= tol
+
+
+@pytest.mark.parametrize('name', [n for n in CLOSED if 'mckf_a' not in n or 'imcckf' in n or 'gmckf' in n])
+def test_block_replay_matches_reference(name):
+    """Open-loop replay of the reference's recorded streams through the per-row form: no feedback, tight gate."""
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    out = rmckf_block.run_replay(f_seq, g['dq_prev'], g['X'][0], g['desired'], meta['gain'], method=meta['method'],
+                                 kernel_bw=p['kernel_bw'], annealing=p['annealing'], k_max=int(meta['t_max'] / meta['dt']))
+    assert rel_err(out['X'][g['X_steps']], g['X']) <= 1e-11
+    assert np.array_equal(out['err'], g['err'])
+    # commanded dq of step k is the regressor of step k+1
+    assert rel_err(out['dq_cmd'][:-1], g['dq_prev'][1:]) <= 1e-9
+    last = int(g['P_steps'][-1])
+    if last == len(g['t']) - 1:
+        assert rel_err(out['P_final'], g['P_blocks'][-1]) <= 1e-11
+
+
+@pytest.mark.parametrize('name', [n for n in CLOSED if 'gmckf' in n or '_kf_' in n or 'imcckf' in n])
+def test_block_closed_loop_matches_reference(name):
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    discs = plant_ref.place_discs()
+    robot = plant_ref.PinholeUR10(meta['dt'])
+    robot.start(g['q_start'])
+    x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 8, 6)
+    assert np.array_equal(x0.ravel(), g['X'][0])
+    out = rmckf_block.run_closed_loop(lambda q: plant_ref.project(plant_ref.fkine_all(q)[5], discs), g['q_start'], g['desired'],
+                                      g['noise'], meta['dt'], meta['t_max'], meta['gain'], x0, method=meta['method'],
+                                      kernel_bw=p['kernel_bw'], annealing=p['annealing'])
+    assert out['status'] == 0 and out['k_done'] == 299
+    horizon = 40 if name in CHAOTIC else 299
+    assert rel_err(out['err'][:horizon], g['err'][:horizon]) <= 1e-9
+    assert rel_err(out['q'][:horizon], g['q'][:horizon]) <= 1e-9
+
+
+def test_stats_known_answers_survey_appendix_b():
+    g = load_golden('closed_gmckf_a1p5')
+    s = rmckf_dense.trial_stats(g['err'], g['t'])
+    assert np.allclose(s, [56047.5204, 5198.02211, 29866.6195], rtol=1e-8)
+    g = load_golden('closed_gmckf_a1p5_anneal')
+    assert np.allclose(rmckf_dense.trial_stats(g['err'], g['t']), [51999.6695, 4960.54063, 28561.2268], rtol=1e-8)
+
+
+def test_plant_goal_pose_projects_onto_desired():
+    discs = plant_ref.place_discs()
+    f = plant_ref.project(plant_ref.fkine_all(plant_ref.Q_GOAL)[5], discs)
+    assert np.abs(f - plant_ref.DESIRED_F).max() < 1e-9
+    assert np.abs(discs[:, 2]).max() < 1e-12                      # discs lie on the floor
