@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RMCKF updates/s over a Monte-Carlo batch (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch: the closed-loop kernel advancing every trial of BASELINE
+config 2 (4 features / 6 DoF, GMCKF = RMCKF, sigma 10, alpha-stable noise alpha = 1.5, 65 536 trials, 299 filter
+updates per trial) from q_start to the end of the trial, with the noise streams already resident in HBM and the
+per-step X / error / joint logs written to HBM.  One *update* = predict + correntropy-weighted correct + control law of
+one filter for one time step.  With N > 1 every rank runs its own 65 536 trials (global trial indices
+rank*65536 ..., so seeds differ) -- weak scaling, no data-path collective -- followed by one RCCL all-gather of the
+per-trial [ISE, IAE, ITAE, status] rows, which is inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')      # before numpy loads OpenBLAS: one BLAS thread per process
+os.environ.setdefault('OMP_NUM_THREADS', '1')
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRIALS_PER_GPU = 65536
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+ALPHA = 1.5
+
+
+def config2():
+    """BASELINE config 2 in the reference's config.json schema."""
+    return {
+        'log_level': 'INFO',
+        'experiments': {'dt': 0.05, 't_max': 15, 'epoch': TRIALS_PER_GPU, 'ibvs_gain': 0.2,
+                        'q_start': [0.0, 0.0, 1.96349541, 0.0, -1.57079633, 0],
+                        'desired_f': [149.0, 145.0, 125.0, 121.0, 101.0, 145.0, 125.0, 169.0],
+                        'visualization': False, 'change_q_start': True, 'seed': 12345},
+        'estimator': {'method': 'GMCKF', 'estimator_params': {'initial_guess': True, 'kernel_bw': 10, 'fpi_threshold': 0.1,
+                                                              'fpi_epoch_max': 1000, 'annealing': False}},
+        'noise': {'type': 'ALPHA_STABLE', 'noise_params': {'alpha': ALPHA, 'beta': 0, 'gamma': 1, 'delta': 0},
+                  'hold': False, 'hold_time': 0.5, 'seed': 123456},
+    }
+
+
+# ---------------------------------------------------------------------------------------------- host-side input generation
+def _noise_chunk(args):
+    import uvs_amd
+    seeds, steps = args
+    return uvs_amd.noise_batch(uvs_amd.NoiseType.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), seeds, 8, steps)
+
+
+def host_noise(seeds, steps, workers):
+    """[steps][8][T] trial-fastest noise buffer, identical to NoiseProfiler streams (numpy PCG64), built on `workers` cores."""
+    chunks = np.array_split(np.asarray(seeds), max(1, len(seeds) // 512))
+    out = np.empty((steps, 8, len(seeds)))
+    pos = 0
+    if workers > 1:
+        with mp.get_context('fork').Pool(workers) as pool:
+            for block in pool.imap(_noise_chunk, [(c, steps) for c in chunks]):
+                out[:, :, pos:pos + len(block)] = block.transpose(1, 2, 0)
+                pos += len(block)
+    else:
+        for c in chunks:
+            block = _noise_chunk((c, steps))
+            out[:, :, pos:pos + len(block)] = block.transpose(1, 2, 0)
+            pos += len(block)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle, "port")
+def _cpu_trial(args):
+    os.environ['OPENBLAS_NUM_THREADS'] = '1'
+    from oracle import noise_ref, plant_ref, rmckf_dense
+    seed, q_start = args
+    cfg = config2()
+    ex = cfg['experiments']
+    stream = noise_ref.NoiseStreamRef(8, noise_ref.ALPHA_STABLE, seed, alpha=ALPHA, beta=0, gamma=1, delta=0)
+    noise = stream.take(299)                                      # noise generation is not part of an "update": pre-draw it
+    it = iter(noise)
+    t0 = time.perf_counter()
+    out = rmckf_dense.run_closed_loop(plant_ref.PinholeUR10(ex['dt']), q_start, ex['desired_f'], lambda: next(it), ex['dt'],
+                                      ex['t_max'], ex['ibvs_gain'], method='GMCKF', kernel_bw=10, annealing=False)
+    return out['k_done'], time.perf_counter() - t0
+
+
+def cpu_baseline(q_starts, budget_trials_per_core=24):
+    """Dense numpy restatement of the reference loop (oracle/rmckf_dense.py, op-for-op experiment.py:125-343) on all host cores."""
+    os.environ['OPENBLAS_NUM_THREADS'] = '1'
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    n_trials = min(len(q_starts), budget_trials_per_core * cores)
+    jobs = [(123456 + i, q_starts[i]) for i in range(n_trials)]
+    t0 = time.perf_counter()
+    with mp.get_context('fork').Pool(cores) as pool:
+        res = pool.map(_cpu_trial, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    updates = sum(r[0] for r in res)
+    single = updates / sum(r[1] for r in res)                     # per-process rate (what one reference process achieves)
+    return {'value': updates / wall, 'unit': 'updates/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_trials} trials x 299 steps of config 2 through oracle/rmckf_dense.py (dense numpy, OPENBLAS_NUM_THREADS=1, '
+                      f'one process per core, noise pre-drawn); os.cpu_count()={os.cpu_count()}',
+            'per_process_updates_per_s': single}
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--trials', type=int, default=TRIALS_PER_GPU, help='trials per GPU (default = BASELINE config 2)')
+    ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
+
+    import uvs_amd
+    from uvs_amd import batch, dist, engine
+
+    cfg = config2()
+    cfg['experiments']['epoch'] = args.trials * world
+    plan = batch.plan_trials(cfg, cells=[ALPHA])                  # global enumeration: trial t -> seed 123456 + t, jitter draw t
+    lo, hi = dist.shard_range(len(plan), rank, world)
+    t_log = engine.loop_clock(0.05, 15)
+    K = len(t_log)
+
+    # ---- everything that forks happens before the GPU is touched
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    workers = max(1, cores // max(1, world))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(plan.q_start)
+    t0 = time.perf_counter()
+    noise_host = host_noise(plan.seed[lo:hi], K, workers)
+    gen_s = time.perf_counter() - t0
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group('nccl', device_id=dev)             # RCCL over xGMI
+    uvs_amd.lib()
+
+    t0 = time.perf_counter()
+    noise = torch.as_tensor(noise_host, device=dev)               # PCIe upload, outside the timed region
+    q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
+    torch.cuda.synchronize()
+    h2d_s = time.perf_counter() - t0
+    del noise_host
+
+    p = cfg['estimator']['estimator_params']
+    fp = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    T = hi - lo
+    # output buffers are allocated once and reused by every step (engine.closed_loop allocates; here we pre-allocate by hand)
+    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev, zero=True) for k, c in (('x', 48), ('err', 8), ('q', 6))}
+    stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    k_done = torch.zeros(T, dtype=torch.int32, device=dev)
+    import ctypes as C
+    flat = lambda t: uvs_amd._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))     # noqa: E731
+    NV = uvs_amd._lib.NULL_VIEW
+
+    def launch():
+        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
+            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise), NV, engine.stream_view(bufs['x']),
+            engine.stream_view(bufs['err']), engine.stream_view(bufs['q']), NV, NV, stats.data_ptr(), status.data_ptr(),
+            k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        uvs_amd._lib.check(rc)
+
+    def one_step():
+        launch()
+        if world > 1:
+            return dist.gather_trial_rows(dist.pack_rows(stats, status), len(plan))
+        return None
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                                               # HIP events on the stream the kernel is launched on
+        launch()
+        e1.record()
+        if world > 1:
+            dist.gather_trial_rows(dist.pack_rows(stats, status), len(plan))
+        kernel_ms.append((e0, e1))
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        td.all_reduce(w, op=td.ReduceOp.MAX)
+        wall = float(w.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in kernel_ms]
+
+    updates_per_launch = int(k_done.sum().item())                 # FAIL trials stop early; count what was actually computed
+    if world > 1:
+        u = torch.tensor([updates_per_launch], dtype=torch.int64, device=dev)
+        td.all_reduce(u)
+        total_updates = int(u.item())
+    else:
+        total_updates = updates_per_launch
+    value = total_updates * args.steps / wall
+
+    if rank == 0:
+        b_alg = 8 * (2 * 8 + 6 + 8 * 6)                           # 560 B / update: noise in, err + X + q out
+        avg_ms = float(np.mean(kernel_ms))
+        achieved = updates_per_launch * b_alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+        if os.path.exists(tr_path):
+            traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')
+        line = {
+            'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, '
+                                   f'{T} trials/GPU x {K} updates, X+err+q logged per step', 'trials_per_gpu': T, 'updates_per_trial': K,
+                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0], 'failed_trials': int((status != 0).sum().item())},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'closed_loop_kernel<8,6,L>', 'avg_kernel_ms': avg_ms,
+                         'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
+            'cpu_baseline': cpu,
+            'setup': {'noise_gen_s': gen_s, 'noise_gen_workers': workers, 'h2d_s': h2d_s,
+                      'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if world == 1 else None},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

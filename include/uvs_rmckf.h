@@ -1,0 +1,154 @@
+/*
+ * uvs_rmckf.h -- C ABI of libuvs_rmckf.so: batched RMCKF Jacobian estimator for
+ * uncalibrated visual servoing on AMD MI355X (gfx950).
+ *
+ * The reference (AI-SPARC/uncalibrated-visual-servoing) has no native code and no
+ * FFI: the estimator is ~35 inline numpy lines inside Experiment.run()
+ * (experiment.py:164-300) and Monte-Carlo trials run sequentially from main.py:121-148.
+ * This header is therefore the boundary a maintainer would bind with ctypes (see
+ * INTEGRATION.md); every entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers owned by the caller; nothing is allocated,
+ *     freed or synchronised inside the library (graph-capture safe).  Work is enqueued
+ *     on the hipStream_t passed as `stream` (void* here; NULL = default stream).
+ *   - Returns 0 on success, <0 on error (never throws); uvs_last_error() gives the text
+ *     for the calling thread.  Thread-safe across distinct streams/devices; no global state.
+ *   - fp64 throughout (numpy default).  Integers: int32 status/k_done.
+ *   - Arrays indexed [trial][step][component] are passed as strided views so that the
+ *     coalesced trial-fastest layout ([step][component][trial]) and the per-trial
+ *     record layout ([trial][step][component]) are both expressible.  Strides are in
+ *     elements (doubles).  A view with base == NULL disables that input/output.
+ *   - m = 2*features (measurement rows), n = joints (regressor length), state X is
+ *     m*n row-major (X.reshape(m, n), experiment.py:300), covariance is the m diagonal
+ *     n x n blocks of the reference's mn x mn P (exactly block diagonal).
+ */
+#ifndef UVS_RMCKF_H
+#define UVS_RMCKF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVS_MAX_M 32          /* measurement rows (16 features)            */
+#define UVS_MAX_N 8           /* joints                                    */
+#define UVS_MAX_POINTS 16
+
+/* return codes */
+#define UVS_OK 0
+#define UVS_ERR_ARG (-1)      /* NULL/ill-formed argument                   */
+#define UVS_ERR_SHAPE (-2)    /* (m, n, lanes_per_filter) not instantiated  */
+#define UVS_ERR_HIP (-3)      /* HIP runtime error (see uvs_last_error)     */
+#define UVS_ERR_METHOD (-4)   /* estimator not available on this path       */
+
+/* experiment.py:6-11 (Method) and :13-15 (ExperimentStatus) */
+enum { UVS_METHOD_ANALYTICAL = 1, UVS_METHOD_KF = 2, UVS_METHOD_MCKF = 3, UVS_METHOD_IMCCKF = 4, UVS_METHOD_GMCKF = 5 };
+enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
+
+/* Strided view of a [trial][step][component] array of doubles. */
+typedef struct uvs_view {
+    double *base;
+    int64_t trial_stride, step_stride, comp_stride;
+} uvs_view;
+
+/* Estimator + control-law parameters: Experiment.__init__ (experiment.py:18-40) and the
+ * constants of run() (:70-76, :119-122, :267-271, :280). */
+typedef struct uvs_filter_params {
+    int32_t m, n;               /* len(desired_f); joints (experiment.py:53-54)                    */
+    int32_t method;             /* UVS_METHOD_*; GMCKF is the paper's RMCKF                         */
+    int32_t annealing;          /* sigma_k = kernel_bw + anneal_span*(1 - k/k_max) (:267-271)       */
+    int32_t k_max;              /* int(t_max/t_s) (:120)                                            */
+    int32_t steps;              /* loop iterations K: number of t = t_s, 2 t_s, ... < t_max (:125)  */
+    int32_t initial_guess;      /* 1: analytic interaction-matrix X0 (:86-114); 0: X0 from view     */
+    int32_t lanes_per_filter;   /* 0 = library default; else 1,2,4,..,m lanes cooperate on a filter */
+    double kernel_bw;           /* sigma_0 (:37)                                                    */
+    double anneal_span;         /* 100 (:271)                                                       */
+    double gain;                /* ibvs_gain lambda (:26, :312)                                     */
+    double dt;                  /* t_s (:24)                                                        */
+    double reg;                 /* 0.001**2 added to Cy before inversion (:280)                     */
+    double desired[UVS_MAX_M];  /* desired_f (:21)                                                  */
+} uvs_filter_params;
+
+/* Synthetic plant (the reference's real plant is an external CoppeliaSim process).
+ *   UVS_PLANT_DH_PINHOLE: DH serial chain + pinhole camera on the last frame looking at fixed points.  Kinematics follow
+ *     ur10_simulation.py:97-139,204-211; camera model and point placement are SURVEY.md Appendix A.
+ *   UVS_PLANT_LINEAR: f = lin_f0 + lin_jacobian (q - lin_q0), a consistent linearised camera for shapes the DH model cannot
+ *     provide (BASELINE config 5: m = 32, n = 7); the three arrays are DEVICE pointers (m*n row-major, m, n doubles). */
+enum { UVS_PLANT_DH_PINHOLE = 0, UVS_PLANT_LINEAR = 1 };
+typedef struct uvs_plant {
+    int32_t n_joints, n_points;
+    double theta_offset[UVS_MAX_N], d[UVS_MAX_N], a[UVS_MAX_N];
+    double cos_alpha[UVS_MAX_N], sin_alpha[UVS_MAX_N];   /* filled by the host with its libm cos/sin(alpha) */
+    double points[UVS_MAX_POINTS][3];                    /* world coordinates of the tracked points           */
+    double focal, center;                                /* u = center + focal*x/z (experiment.py:97)         */
+    int32_t kind, reserved;
+    const double *lin_jacobian, *lin_f0, *lin_q0;
+} uvs_plant;
+
+/* Library identification. */
+const char *uvs_version(void);
+const char *uvs_last_error(void);
+/* Lanes-per-filter variants compiled for (m, n): writes up to `cap` values, returns the count. */
+int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap);
+
+/*
+ * Closed-loop Monte-Carlo batch: T independent servo trials, each the whole while-loop of
+ * Experiment.run() (experiment.py:125-343) on the synthetic plant, one HIP grid.
+ * Replaces main.py:121-148 (sequential trials) + experiment.py:48-359.
+ *   q_start  [T][1][n]   in   start joints (main.py:129-134 jitter already applied)
+ *   noise    [T][K][m]   in   per-step measurement noise (NoiseProfiler.getNoise(), noise.py:81-118); NULL = none
+ *   x0       [T][1][m*n] in   initial state when !initial_guess
+ *   x_out    [T][K][m*n] out  X after the update of step k                (NULL to skip)
+ *   err_out  [T][K][m]   out  f - desired_f (error_log, experiment.py:327)
+ *   q_out    [T][K][n]   out  joints at step k (q_log, :323)
+ *   f_out    [T][K][m]   out  noisy features (f_log, :325)
+ *   dq_out   [T][K][n]   out  commanded joint rate (:312)
+ *   stats    [T][3]      out  ||ISE||_2, ||IAE||_2, ||ITAE||_2 over features (results/plot_errorbar.m:39-84)
+ *   status   [T] int32   out  UVS_STATUS_* ; FAIL when X turns non-finite (pinv raises, :313-316)
+ *   k_done   [T] int32   out  rows logged (k at exit, :345)
+ *   x_final  [T][1][m*n], p_final [T][1][m*n*n] out  state after the last step (NULL to skip)
+ */
+int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T,
+                              uvs_view q_start, uvs_view noise, uvs_view x0,
+                              uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
+                              double *stats, int32_t *status, int32_t *k_done,
+                              uvs_view x_final, uvs_view p_final, void *stream);
+
+/*
+ * Open-loop replay of recorded streams through the estimator + control law
+ * (experiment.py:166-312 without the plant): the parity workhorse.
+ *   f        [T][K+1][m]  in   observed features; row 0 is f_old of the first step (:128)
+ *   dq       [T][K][n]    in   regressor of step k (previous command, :188); row 0 ignored (H = 0, :183)
+ *   x0       [T][1][m*n]  in
+ *   x_out    [T][K][m*n], err_out [T][K][m], kappa_out [T][K][m], dqcmd_out [T][K][n]  out (NULL to skip)
+ *   status   [T] int32, k_done [T] int32  out
+ */
+int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs_view dq, uvs_view x0,
+                         uvs_view x_out, uvs_view err_out, uvs_view kappa_out, uvs_view dqcmd_out,
+                         int32_t *status, int32_t *k_done, uvs_view x_final, uvs_view p_final, void *stream);
+
+/*
+ * One estimator + control step for T filters whose state lives in HBM between calls: what
+ * Experiment.run() does between getCameraImage() and setJointsPos() (experiment.py:166-312) when
+ * the robot is external (live simulator).  All arrays contiguous, trial-major.
+ *   X [T][m*n] inout, P [T][m][n][n] inout, f [T][m], f_old [T][m], dq_prev [T][n] in
+ *   first: 1 on the first iteration (H = 0, :183-184); k: loop index for annealing (:270)
+ *   dq_out [T][n], err_out [T][m], kappa_out [T][m] out; status [T] int32 out (FAIL = non-finite X)
+ */
+int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double *P, const double *f,
+                       const double *f_old, const double *dq_prev, int32_t first, int32_t k,
+                       double *dq_out, double *err_out, double *kappa_out, int32_t *status, void *stream);
+
+/*
+ * Per-trial ISE/IAE/ITAE norms from an error trajectory (results/plot_errorbar.m:39-84).
+ *   err [T][K][m] in, t [K] in (device), k_done [T] in (NULL = K rows), stats [T][3] out
+ */
+int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const double *t, const int32_t *k_done,
+                         double *stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVS_RMCKF_H */

@@ -80,15 +80,17 @@ def run_replay(f_seq, dq_seq, x0, desired_f, gain, method=GMCKF, kernel_bw=10.0,
 
 
 def run_closed_loop(plant, q_start, desired_f, noise_seq, t_s, t_max, gain, x0, method=GMCKF,
-                    kernel_bw=10.0, annealing=False):
+                    kernel_bw=10.0, annealing=False, initial_guess=True):
     """Closed loop on a functional plant: ``plant(q) -> f`` (noise-free features at joints q).
-    ``noise_seq`` (K, m) or None.  Returns err (k, m), q (k, n), X (k, mn), t (k,), status, k_done."""
+    ``noise_seq`` (K, m) or None.  ``initial_guess`` selects what the first ``f_old`` is: the noise-free features seen while
+    forming the analytic X0 (experiment.py:90) or zeros when X0 is supplied (experiment.py:56).
+    Returns err (k, m), q (k, n), X (k, mn), t (k,), status, k_done."""
     desired_f = np.asarray(desired_f, float)
     m, n = len(desired_f), len(q_start)
     k_max = int(t_max / t_s)
     filt = BlockFilter(m, n, x0, method, kernel_bw, annealing, k_max)
     q = np.array(q_start, float)
-    f = plant(q)
+    f = plant(q) if initial_guess else np.zeros(m)
     dq = np.zeros(n)
     t, k = t_s, 0                                                   # start() steps the clock once
     ts, errs, qs, Xs = [], [], [], []

@@ -1,0 +1,267 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference fixtures and the oracle.  All tests need an MI355X."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CLOSED = [n for n in golden_names('closed_') if '_mckf_' not in n]          # KF / IMCCKF / GMCKF fixtures
+CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
+LANES_86 = (1, 2, 4, 8)
+
+
+@pytest.fixture(scope='module')
+def uvs():
+    import torch
+    assert torch.cuda.is_available()
+    import uvs_amd
+    uvs_amd.lib()
+    return uvs_amd
+
+
+def _cuda(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), device='cuda')
+
+
+def _fp(uvs, g, lanes=0, steps=None, **kw):
+    meta, p = g['meta'], g['meta']['params']
+    return uvs.engine.make_params(8, 6, meta['method'], p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'],
+                                  g['desired'], p['initial_guess'], lanes, steps, **kw)
+
+
+# ---------------------------------------------------------------------------------------------- open-loop replay
+@pytest.mark.parametrize('lanes', LANES_86)
+@pytest.mark.parametrize('name', CLOSED)
+def test_replay_matches_reference(uvs, name, lanes):
+    """Feed the reference's recorded f / dq streams through the kernel: per-step X within 1e-10 (contract 1e-5)."""
+    g = load_golden(name)
+    K = len(g['t'])
+    fp = _fp(uvs, g, lanes)
+    f_seq = np.vstack([g['f_init'][None], g['f']])                           # (K+1, 8)
+    T = 3                                                                    # same trial three times: lanes must agree bitwise
+    f = _cuda(np.repeat(f_seq[:, :, None], T, axis=2))
+    dq = _cuda(np.repeat(g['dq_prev'][:, :, None], T, axis=2))
+    x0 = _cuda(np.tile(g['X'][0], (T, 1)))
+    out = uvs.engine.replay(fp, f, dq, x0, final_state=True)
+    X = out['x'].cpu().numpy()
+    assert np.array_equal(X[:, :, 0], X[:, :, 1]) and np.array_equal(X[:, :, 0], X[:, :, 2])
+    assert rel_err(X[g['X_steps'], :, 0], g['X']) <= 1e-10
+    assert np.array_equal(out['err'].cpu().numpy()[:, :, 0], g['err'])
+    assert rel_err(out['dqcmd'].cpu().numpy()[:-1, :, 0], g['dq_prev'][1:]) <= 1e-9
+    if g['meta']['method'] == 'GMCKF':
+        kap = out['kappa'].cpu().numpy()[:, :, 0]
+        ref = np.exp(-0.5 * g['e'] ** 2 / g['sigma'][:, None] ** 2)
+        assert np.all(kap > 0 - 1e-300) and np.all(kap <= 1.0) and rel_err(kap, ref) <= 1e-9
+    if int(g['P_steps'][-1]) == K - 1:
+        P = out['p_final'].cpu().numpy()[0].reshape(8, 6, 6)
+        assert rel_err(P, g['P_blocks'][-1]) <= 1e-10
+        assert np.array_equal(P, np.transpose(P, (0, 2, 1)))
+    assert int(out['status'].sum()) == 0 and int(out['k_done'][0]) == K
+
+
+# ---------------------------------------------------------------------------------------------- closed loop
+@pytest.mark.parametrize('lanes', LANES_86)
+@pytest.mark.parametrize('name', CLOSED)
+def test_closed_loop_matches_reference(uvs, name, lanes):
+    """Whole trial in the kernel (plant + estimator + control) on the reference's noise: trajectories within 1e-8."""
+    g = load_golden(name)
+    K = len(g['t'])
+    fp = _fp(uvs, g, lanes)
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:, :, None]),
+                                 want=('x', 'err', 'q', 'f', 'dq'))
+    assert int(out['status'][0]) == int(g['status']) and int(out['k_done'][0]) == K
+    horizon = 40 if name in CHAOTIC else K
+    tol = 1e-8
+    err, q, X = (out[k].cpu().numpy()[:, :, 0] for k in ('err', 'q', 'x'))
+    assert rel_err(err[:horizon], g['err'][:horizon]) <= tol
+    assert rel_err(q[:horizon], g['q'][:horizon]) <= tol
+    assert rel_err(out['f'].cpu().numpy()[:horizon, :, 0], g['f'][:horizon]) <= tol
+    steps = g['X_steps'][g['X_steps'] < horizon]
+    assert rel_err(X[steps], g['X'][:len(steps)]) <= tol
+    assert rel_err(out['dq'].cpu().numpy()[:horizon - 1, :, 0], g['dq_prev'][1:horizon]) <= 1e-7
+    if name not in CHAOTIC:
+        from oracle.rmckf_dense import trial_stats
+        assert rel_err(out['stats'].cpu().numpy()[0], trial_stats(g['err'], g['t'])) <= 1e-8
+
+
+def test_initial_guess_matches_reference(uvs):
+    g = load_golden('closed_gmckf_a1p5_jitter')
+    fp = _fp(uvs, g, steps=1)
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:1, :, None]), want=('x', 'f'))
+    assert rel_err(out['x'].cpu().numpy()[0, :, 0], g['X'][0]) <= 1e-12      # step 0: H = 0 so X stays X0
+    assert rel_err(out['f'].cpu().numpy()[0, :, 0], g['f'][0]) <= 1e-13
+
+
+# ---------------------------------------------------------------------------------------------- drop-in API
+@pytest.mark.parametrize('name', ['closed_gmckf_a1p5', 'closed_gmckf_mix_anneal', 'closed_kf_a2p0', 'closed_imcckf_a1p5'])
+def test_experiment_api_drop_in(uvs, name):
+    """Experiment(...).run() with the reference's call signature returns the reference's 9-tuple."""
+    g = load_golden(name)
+    meta = g['meta']
+    NT, M = uvs.NoiseType, uvs.Method
+    prof = uvs.NoiseProfiler(num_features=8, noise_type=NT[meta['noise_type']], seed=meta['seed'], noise_hold=meta['hold'],
+                             noise_hold_cnt=meta['hold_cnt'], noise_params=meta['noise_params'])
+    ex = uvs.Experiment(q_start=g['q_start'], desired_f=g['desired'], noise_prof=prof, t_s=meta['dt'], t_max=meta['t_max'],
+                        ibvs_gain=meta['gain'], robot=uvs.SyntheticRobot(dt=meta['dt']), method=M[meta['method']],
+                        method_params=meta['params'])
+    status, t, err, q, f, fd, cam, noise, bw = ex.run()
+    assert status == uvs.ExperimentStatus.SUCCESS and status.value == int(g['status'])
+    assert np.array_equal(t, g['t']) and np.array_equal(noise, g['noise'])
+    for got, ref in ((err, g['err']), (q, g['q']), (f, g['f']), (cam, g['cam'])):
+        assert got.shape == ref.shape and rel_err(got, ref) <= 1e-8
+    assert np.array_equal(fd, np.tile(g['desired'], (len(t), 1))) and np.all(bw == -1)
+
+
+def test_experiment_api_with_external_robot(uvs):
+    """A robot the package knows nothing about (the oracle's duck-typed plant): per-step estimator on the GPU."""
+    from oracle.plant_ref import PinholeUR10
+    g = load_golden('closed_gmckf_a1p5_anneal')
+    meta = g['meta']
+    prof = uvs.NoiseProfiler(8, uvs.NoiseType.ALPHA_STABLE, seed=meta['seed'], noise_params=meta['noise_params'])
+    ex = uvs.Experiment(g['q_start'], g['desired'], prof, meta['dt'], meta['t_max'], meta['gain'], PinholeUR10(meta['dt']),
+                        uvs.Method.GMCKF, **meta['params'])
+    status, t, err, q, f, fd, cam, noise, bw = ex.run()
+    assert status == uvs.ExperimentStatus.SUCCESS and len(t) == 299
+    assert np.array_equal(t, g['t']) and np.array_equal(noise, g['noise'])
+    assert rel_err(err, g['err']) <= 1e-8 and rel_err(q, g['q']) <= 1e-8 and rel_err(cam, g['cam']) <= 1e-8
+
+
+def test_mckf_is_refused_loudly(uvs):
+    with pytest.raises(NotImplementedError):
+        uvs.Experiment([0] * 6, [0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.MCKF, initial_guess=True,
+                       kernel_bw=10, fpi_threshold=0.1, fpi_epoch_max=10, annealing=False).run()
+
+
+# ---------------------------------------------------------------------------------------------- other shapes
+def _random_replay_case(m, n, K, T, seed):
+    rng = np.random.default_rng(seed)
+    J = rng.normal(size=(T, m, n)) * 20
+    dq = rng.normal(size=(T, K, n)) * 0.3
+    f = np.zeros((T, K + 1, m))
+    f[:, 0] = rng.uniform(60, 200, (T, m))
+    for k in range(K):
+        f[:, k + 1] = f[:, k] + np.einsum('tmn,tn->tm', J, dq[:, k]) * 0.05 + rng.standard_t(2, size=(T, m))
+    x0 = (J + rng.normal(size=J.shape)).reshape(T, m * n)
+    return f, dq, x0, rng.uniform(80, 180, m)
+
+
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF'])
+@pytest.mark.parametrize('m,n,lanes', [(2, 6, 1), (6, 6, 1), (8, 6, 1), (8, 6, 4), (32, 7, 8), (32, 7, 16), (32, 7, 32)])
+def test_replay_other_shapes_match_block_oracle(uvs, m, n, lanes, method):
+    """Shapes the reference cannot run (experiment.py hard-wires m = 8, n = 6): oracle = per-row restatement."""
+    from oracle import rmckf_block
+    K, T = 40, 5
+    f, dq, x0, des = _random_replay_case(m, n, K, T, 1000 + m)
+    fp = uvs.engine.make_params(m, n, method, 7.5, True, 0.05, 15, 0.2, des, False, lanes, steps=K)
+    out = uvs.engine.replay(fp, _cuda(f.transpose(1, 2, 0)), _cuda(dq.transpose(1, 2, 0)), _cuda(x0), final_state=True)
+    for t in range(T):
+        ref = rmckf_block.run_replay(f[t], dq[t], x0[t], des, 0.2, method, 7.5, True, 300)
+        assert rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']) <= 1e-10
+        assert rel_err(out['dqcmd'].cpu().numpy()[:, :, t], ref['dq_cmd']) <= 1e-8
+        assert rel_err(out['kappa'].cpu().numpy()[:, :, t], ref['kappa']) <= 1e-9
+        assert rel_err(out['p_final'].cpu().numpy()[t].reshape(m, n, n), ref['P_final']) <= 1e-10
+
+
+@pytest.mark.parametrize('lanes', [8, 16, 32])
+def test_closed_loop_stress_plant(uvs, lanes):
+    """(m, n) = (32, 7) on the linear consistent plant (BASELINE config 5), closed loop, against the block oracle."""
+    from oracle import rmckf_block
+    plant = uvs.LinearPlant.random(32, 7, seed=2)
+    K, T = 80, 4
+    rng = np.random.default_rng(5)
+    q_goal = plant.q0 + rng.uniform(-0.3, 0.3, 7)
+    des = plant.features(q_goal)
+    q0 = q_goal + rng.uniform(-0.15, 0.15, (T, 7))
+    noise = rng.standard_t(3, size=(T, K, 32)) * 0.5
+    x0 = np.tile((plant.J * (1 + 0.1 * rng.normal(size=plant.J.shape))).ravel(), (T, 1))
+    fp = uvs.engine.make_params(32, 7, 'GMCKF', 10.0, False, 0.05, 15, 0.2, des, False, lanes, steps=K)
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), _cuda(x0), want=('x', 'err', 'q'))
+    for t in range(T):
+        ref = rmckf_block.run_closed_loop(plant.features, q0[t], des, noise[t], 0.05, 0.05 * (K + 0.5), 0.2, x0[t], initial_guess=False)
+        assert ref['k_done'] == K and ref['status'] == 0
+        assert rel_err(out['err'].cpu().numpy()[:, :, t], ref['err']) <= 1e-8
+        assert rel_err(out['q'].cpu().numpy()[:, :, t], ref['q']) <= 1e-8
+        assert rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']) <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------------- failure semantics
+def test_non_finite_state_fails_the_trial_only(uvs):
+    g = load_golden('closed_gmckf_a1p5')
+    K, T, bad_step = 50, 6, 17
+    fp = _fp(uvs, g, steps=K)
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    noise = np.repeat(g['noise'][:K, :, None], T, axis=2)
+    noise[bad_step, 3, 2] = np.nan                                           # trial 2 sees a NaN measurement
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(np.tile(g['q_start'], (T, 1))), _cuda(noise), want=('err', 'x'))
+    status, k_done = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
+    assert list(status) == [0, 0, 1, 0, 0, 0] and k_done[2] == bad_step and np.all(np.delete(k_done, 2) == K)
+    err = out['err'].cpu().numpy()
+    assert np.array_equal(err[:, :, 0], err[:, :, 5]) and rel_err(err[:, :, 0], g['err'][:K]) <= 1e-8
+    assert np.array_equal(err[:bad_step, :, 2], err[:bad_step, :, 0]) and np.all(err[bad_step:, :, 2] == 0)
+
+
+# ---------------------------------------------------------------------------------------------- statistics kernel
+def test_stats_kernel_matches_matlab_definition(uvs):
+    from oracle.rmckf_dense import trial_stats
+    rng = np.random.default_rng(3)
+    K, T = 299, 37
+    err = rng.normal(size=(T, K, 8)) * 10
+    t = uvs.engine.loop_clock(0.05, 15)
+    k_done = rng.integers(1, K + 1, T).astype(np.int32)
+    got = uvs.engine.stats_reduce(_cuda(err.transpose(1, 2, 0)), t, _cuda(k_done)).cpu().numpy()
+    for j in range(T):
+        assert rel_err(got[j], trial_stats(err[j, :k_done[j]], t[:k_done[j]])) <= 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_batch_properties(uvs):
+    """BASELINE config 2 size (65 536 trials x 299 steps): results do not depend on batch position or launch
+    partition, duplicates are bit-identical, sampled trials match the oracle, kappa/stat invariants hold."""
+    import torch
+    from oracle import plant_ref, rmckf_block, rmckf_dense
+    g = load_golden('closed_gmckf_a1p5')
+    meta = g['meta']
+    T, K = 65536, 299
+    fp = _fp(uvs, g)
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    noise = torch.empty((K, 8, T), dtype=torch.float64, device='cuda')
+    noise.cauchy_(generator=gen)                                             # impulsive, like alpha = 1
+    noise.clamp_(-1e4, 1e4)
+    q0 = torch.as_tensor(g['q_start'], device='cuda').repeat(T, 1)
+    q0[:, 0] -= torch.rand(T, generator=gen, device='cuda', dtype=torch.float64) * 0.3
+    q0[:, 1] -= torch.rand(T, generator=gen, device='cuda', dtype=torch.float64) * 0.6
+    noise[:, :, 0] = torch.as_tensor(g['noise'], device='cuda')              # trial 0 = the reference fixture
+    q0[0] = torch.as_tensor(g['q_start'], device='cuda')
+    noise[:, :, T - 1] = noise[:, :, 12345]                                  # duplicate of another trial, far away in the grid
+    q0[T - 1] = q0[12345]
+    full = uvs.engine.closed_loop(fp, plant.to_struct(), q0, noise, want=('err',))
+    err = full['err']
+    assert rel_err(err[:, :, 0].cpu().numpy(), g['err']) <= 1e-8
+    assert torch.equal(err[:, :, T - 1], err[:, :, 12345]) and torch.equal(full['stats'][T - 1], full['stats'][12345])
+    # partition invariance: an odd-sized slice run on its own reproduces the same bits
+    lo, hi = 30001, 30001 + 4097
+    part = uvs.engine.closed_loop(fp, plant.to_struct(), q0[lo:hi].contiguous(), noise[:, :, lo:hi].contiguous(), want=('err',))
+    assert torch.equal(part['err'], err[:, :, lo:hi]) and torch.equal(part['stats'], full['stats'][lo:hi])
+    assert torch.equal(part['status'], full['status'][lo:hi]) and torch.equal(part['k_done'], full['k_done'][lo:hi])
+    # stats kernel == fused stats
+    ok = full['status'] == 0
+    s2 = uvs.engine.stats_reduce(err, uvs.engine.loop_clock(meta['dt'], meta['t_max']), full['k_done'])
+    assert torch.allclose(s2[ok], full['stats'][ok], rtol=1e-12, atol=0)
+    # sampled trials against the oracle (short horizon: heavy-tailed closed loops amplify rounding later on)
+    discs = plant_ref.place_discs()
+    H = 25
+    for t in (7, 4242, 65000):
+        robot = plant_ref.PinholeUR10(meta['dt'])
+        robot.start(q0[t].cpu().numpy())
+        x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 8, 6)
+        ref = rmckf_block.run_closed_loop(lambda qq: plant_ref.project(plant_ref.fkine_all(qq)[5], discs), q0[t].cpu().numpy(),
+                                          g['desired'], noise[:, :, t].cpu().numpy(), meta['dt'], meta['dt'] * (H + 0.5), meta['gain'], x0)
+        assert rel_err(err[:H, :, t].cpu().numpy(), ref['err']) <= 1e-7
+    assert int((full['status'] != 0).sum()) < T // 100

@@ -1,0 +1,171 @@
+"""Monte-Carlo driver: what main.py of the reference does, as one HIP grid per sweep instead of sequential trials.
+
+Keeps the reference's ``config.json`` schema (main.py:16-98), sweep cells (``linspace(0, .2, 12)`` of rho, or
+``linspace(1, 2, 12)`` of alpha for ALPHA_STABLE, main.py:104-106), global trial numbering, per-trial noise seed
+``seed + trial`` (main.py:137-139), the q_start jitter stream ``NoiseProfiler(2, UNIFORM, seed=experiment_seed)`` with
+the ``2 (r - 1)`` formula (main.py:118, 132-134) and the 43-column results.csv (main.py:152-196).
+"""
+import json
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import dist, engine
+from .experiment import ExperimentStatus, Method
+from .noise import NoiseProfiler, NoiseType, noise_batch
+from .plant import SyntheticPlant
+
+REQUIRED = {'experiments': ('dt', 't_max', 'epoch', 'ibvs_gain', 'q_start', 'desired_f', 'visualization', 'change_q_start', 'seed'),
+            'estimator': ('method', 'estimator_params'),
+            'noise': ('type', 'noise_params', 'hold', 'hold_time', 'seed')}
+
+
+def load_config(path_or_dict):
+    """Parse and validate a reference-format config (main.py:16-98); unknown method / noise names and missing keys raise."""
+    cfg = path_or_dict if isinstance(path_or_dict, dict) else json.load(open(path_or_dict, 'r', encoding='utf-8'))
+    if 'log_level' not in cfg:
+        raise KeyError('log_level')
+    for section, keys in REQUIRED.items():
+        for key in keys:
+            if key not in cfg[section]:
+                raise KeyError(f'{section}.{key}')
+    if cfg['estimator']['method'] not in Method.__members__:
+        raise ValueError('Estimation method ' + cfg['estimator']['method'] + ' unknown.')
+    if cfg['noise']['type'] not in NoiseType.__members__:
+        raise ValueError('Noise type ' + cfg['noise']['type'] + ' unknown.')
+    return cfg
+
+
+def sweep_cells(noise_type):
+    return np.linspace(1, 2, 12) if noise_type == NoiseType.ALPHA_STABLE else np.linspace(0, 0.2, 12)   # main.py:104-106
+
+
+@dataclass
+class TrialPlan:
+    """Global enumeration of a sweep: trial t belongs to cell ``cell[t]`` with swept value ``value[t]``."""
+    cell: np.ndarray
+    value: np.ndarray
+    seed: np.ndarray
+    q_start: np.ndarray
+    cells: np.ndarray = field(default=None)
+
+    def __len__(self):
+        return len(self.cell)
+
+
+def plan_trials(cfg, cells=None, epoch=None):
+    """Enumerate trials like main.py:121-139.  ``cells`` overrides the 12-point sweep (e.g. [1.5]); ``epoch`` the trials per cell."""
+    ex, nz = cfg['experiments'], cfg['noise']
+    noise_type = NoiseType[nz['type']]
+    cells = sweep_cells(noise_type) if cells is None else np.asarray(cells, float)
+    epoch = int(ex['epoch'] if epoch is None else epoch)
+    T = len(cells) * epoch
+    q0 = np.tile(np.asarray(ex['q_start'], float), (T, 1))
+    if ex['change_q_start']:
+        # two UNIFORM generators seeded seed and seed + 10 (noise.py:70); trial t consumes the t-th draw of each
+        g0, g1 = (NoiseProfiler(2, NoiseType.UNIFORM, seed=ex['seed']).generators[i] for i in range(2))
+        q0[:, 0] += 2 * (g0.random(T) - 1) * (np.pi / 18)           # main.py:133
+        q0[:, 1] += 2 * (g1.random(T) - 1) * (np.pi / 9)            # main.py:134
+    seed0 = nz['seed']
+    seeds = (seed0 + np.arange(T)) if seed0 is not None else np.full(T, -1)
+    return TrialPlan(cell=np.repeat(np.arange(len(cells)), epoch), value=np.repeat(cells, epoch), seed=seeds, q_start=q0, cells=cells)
+
+
+def trial_noise(cfg, plan, lo, hi, steps, out):
+    """Fill ``out`` (logical [trial][step][m] array-like covering trials lo..hi) with the reference's noise streams."""
+    nz = cfg['noise']
+    noise_type = NoiseType[nz['type']]
+    m = len(cfg['experiments']['desired_f'])
+    hold_cnt = int(nz['hold_time'] / cfg['experiments']['dt'])      # main.py:137
+    key = 'alpha' if noise_type == NoiseType.ALPHA_STABLE else 'rho'
+    for c in np.unique(plan.cell[lo:hi]):
+        idx = np.nonzero(plan.cell[lo:hi] == c)[0]
+        params = dict(nz['noise_params'])
+        params[key] = float(plan.cells[c])                          # main.py:123-126
+        block = noise_batch(noise_type, params, plan.seed[lo:hi][idx], m, steps, nz['hold'], hold_cnt)
+        out[idx] = block
+    return out
+
+
+@dataclass
+class BatchResult:
+    plan: TrialPlan
+    lo: int
+    hi: int
+    t: np.ndarray
+    stats: object            # (T_local, 3) cuda tensor
+    status: object           # (T_local,) int32 cuda tensor
+    k_done: object
+    streams: dict            # optional per-step tensors, trial-fastest [K][comp][T_local]
+    noise: object
+    seconds: float = 0.0
+
+
+def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('err',), lanes=0, noise_tensor=None,
+              device='cuda'):
+    """Run this rank's shard of the sweep on its GPU.  Returns a BatchResult whose tensors stay on the device."""
+    import torch
+    cfg = load_config(cfg)
+    ex, est = cfg['experiments'], cfg['estimator']
+    method = Method[est['method']]
+    if method not in (Method.KF, Method.IMCCKF, Method.GMCKF):
+        raise NotImplementedError(f'{method.name} is not on the HIP path (KF, IMCCKF, GMCKF are)')
+    plant = SyntheticPlant.ur10(ex['desired_f']) if plant is None else plant
+    plan = plan_trials(cfg, cells, epoch)
+    lo, hi = dist.shard_range(len(plan), rank, world)
+    p = est['estimator_params']
+    m, n = len(ex['desired_f']), plant.n_joints
+    fp = engine.make_params(m, n, method.name, p.get('kernel_bw', 1.0), p.get('annealing', False), ex['dt'], ex['t_max'],
+                            ex['ibvs_gain'], ex['desired_f'], p['initial_guess'], lanes)
+    t_log = engine.loop_clock(ex['dt'], ex['t_max'])
+    K, Tl = len(t_log), hi - lo
+    dev = torch.device(device)
+    if noise_tensor is None:
+        host = np.empty((K, m, Tl))
+        trial_noise(cfg, plan, lo, hi, K, host.transpose(2, 0, 1))  # logical [trial][step][m] view of the trial-fastest buffer
+        noise_tensor = torch.as_tensor(host, device=dev)
+    q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
+    x0 = None
+    if not p['initial_guess']:
+        x0 = torch.as_tensor(np.asarray(p['x0'], float).reshape(1, m * n).repeat(Tl, 0), device=dev)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    out = engine.closed_loop(fp, plant.to_struct(), q0, noise_tensor, x0, want=want)
+    stop.record()
+    stop.synchronize()
+    return BatchResult(plan, lo, hi, t_log, out['stats'], out['status'], out['k_done'],
+                       {k: out[k] for k in ('x', 'err', 'q', 'f', 'dq') if out.get(k) is not None}, noise_tensor,
+                       start.elapsed_time(stop) * 1e-3)
+
+
+CSV_COLUMNS = (['experiment_id', 'status', 'rho', 't'] + [f'q_{i}' for i in range(1, 7)] +
+               ['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw'] +
+               [f'f_{i}' for i in range(1, 9)] + [f'desired_f_{i}' for i in range(1, 9)] + [f'noise_{i}' for i in range(1, 9)] + ['kernel_bw'])
+
+
+def write_results_csv(result, cfg, plant, path):
+    """results.csv in the reference's long format (main.py:152-196): one row per logged step, 43 columns.  Needs the
+    'q' and 'f' streams; meant for sweeps of the reference's size (~10^3 trials) -- larger runs keep tensors/npz."""
+    import pandas as pd
+    q = result.streams['q'].cpu().numpy()
+    f = result.streams['f'].cpu().numpy()
+    noise = result.noise.cpu().numpy()
+    status, k_done = result.status.cpu().numpy(), result.k_done.cpu().numpy()
+    desired = np.asarray(cfg['experiments']['desired_f'], float)
+    header = not os.path.exists(path)
+    for j in range(result.hi - result.lo):
+        k = int(k_done[j])
+        cam = np.zeros((k, 6))
+        for i in range(k):
+            cam[i, :3] = plant.fkine_all(q[i, :, j])[-1][:3, 3]
+        cols = {'experiment_id': result.lo + j, 'status': ExperimentStatus(int(status[j])), 'rho': result.plan.value[result.lo + j],
+                't': result.t[:k]}
+        cols.update({f'q_{i + 1}': q[:k, i, j] for i in range(6)})
+        cols.update({name: cam[:, i] for i, name in enumerate(CSV_COLUMNS[10:16])})
+        cols.update({f'f_{i + 1}': f[:k, i, j] for i in range(8)})
+        cols.update({f'desired_f_{i + 1}': np.full(k, desired[i]) for i in range(8)})
+        cols.update({f'noise_{i + 1}': noise[:k, i, j] for i in range(8)})
+        cols['kernel_bw'] = np.full(k, -1.0)                        # -1 unless MCKF (experiment.py:330)
+        pd.DataFrame(data=cols).to_csv(path, mode='a', index=False, header=header)
+        header = False

@@ -1,0 +1,420 @@
+// Device-side building blocks of the batched RMCKF estimator (gfx950 / CDNA4, wave64, fp64).
+//
+// Work decomposition.  A *filter* is one Monte-Carlo trial's estimator: m rows x_i (n doubles each)
+// and m covariance blocks P_i (n x n, symmetric, stored packed), all rows sharing the regressor
+// h = dq (experiment.py:188: H = kron(I_m, dq^T) makes the reference's mn x mn P exactly block
+// diagonal).  L lanes of a wavefront cooperate on one filter, each owning
+// R = m / L consecutive rows in registers; 64 / L filters ride in one wavefront.  L = 1 is
+// "one filter per lane": no cross-lane traffic at all.  L > 1 trades registers for wavefront
+// shuffles (xor butterflies inside the L-lane group) in the innovation norm, the least-squares
+// control law and the final statistics.
+//
+// Everything here is templated on (M, N, L) and fully unrolled so that every array lives in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "uvs_rmckf.h"
+
+namespace uvs {
+
+#define UVS_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- cross-lane helpers
+// Sum over the L consecutive lanes of a group; every lane receives the bit-identical total
+// (xor butterfly: both partners add the same two operands).
+template <int L>
+UVS_DEV double group_sum(double v) {
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int L>
+UVS_DEV int group_or(int v) {
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+// Value held by the lane whose group-relative index is `owner` (others pass anything).
+template <int L>
+UVS_DEV double group_pick(double v, int sub, int owner) {
+    if constexpr (L == 1) return v;
+    return group_sum<L>(sub == owner ? v : 0.0);
+}
+
+UVS_DEV bool finite64(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000LL) != 0x7ff0000000000000LL; }
+
+// ---------------------------------------------------------------- strided views
+struct View {
+    double *p;
+    long long st, sk, sc;
+    UVS_DEV bool on() const { return p != nullptr; }
+    UVS_DEV double *at(long long t, long long k, long long c) const { return p + t * st + k * sk + c * sc; }
+};
+static inline View to_view(const uvs_view &v) { return View{v.base, v.trial_stride, v.step_stride, v.comp_stride}; }
+
+// ---------------------------------------------------------------- packed symmetric n x n
+template <int N>
+struct Sym {
+    static constexpr int NP = N * (N + 1) / 2;
+    __host__ __device__ static constexpr int at(int l, int j) {
+        return l <= j ? l * N - l * (l - 1) / 2 + (j - l) : j * N - j * (j - 1) / 2 + (l - j);
+    }
+};
+
+// ---------------------------------------------------------------- estimator rows
+// sigma_k (experiment.py:267-271)
+UVS_DEV double bandwidth(const uvs_filter_params &fp, int k) {
+    return fp.annealing ? fp.kernel_bw + fp.anneal_span * (1.0 - (double)k / (double)fp.k_max) : fp.kernel_bw;
+}
+// utils.py:171-172 with numpy's evaluation order: ((-0.5 * e*e) / (bw*bw))
+UVS_DEV double gaussian_kernel(double e, double bw) { return exp((-0.5 * (e * e)) / (bw * bw)); }
+
+template <int M, int N, int L>
+struct Rows {
+    static constexpr int R = M / L;
+    static constexpr int NP = Sym<N>::NP;
+    static_assert(M % L == 0, "lanes per filter must divide m");
+    double x[R][N];
+    double p[R][NP];
+
+    UVS_DEV void init_cov() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int l = 0; l < N; ++l)
+#pragma unroll
+                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = (l == j) ? 1.0 : 0.0;   // P = I (experiment.py:73)
+        }
+    }
+
+    // One predict + correct for the R rows of this lane (experiment.py:166-297 in row form):
+    //   P_i += I; nu_i = z_i - x_i.h; weight; g = P_i h; a = h.g; gamma; x_i += gamma g nu_i;
+    //   Joseph with R = 1 collapses to the symmetric rank-1 downdate P_i -= gamma (2 - gamma (a + 1)) g g^T.
+    // kap[] receives the correntropy weights kappa_i that the control law re-uses (experiment.py:308).
+    UVS_DEV void update(const uvs_filter_params &fp, const double (&z)[R], const double (&h)[N], double sigma, double (&kap)[R]) {
+        double nu[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(x[r][j], h[j], acc);
+            nu[r] = z[r] - acc;                                                  // innovation (experiment.py:274)
+        }
+        double c_shared = 1.0;
+        if (fp.method == UVS_METHOD_IMCCKF) {                                    // experiment.py:258-261
+            double ss = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ss = fma(nu[r], nu[r], ss);
+            c_shared = gaussian_kernel(sqrt(group_sum<L>(ss)), sigma);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double g[N];
+#pragma unroll
+            for (int l = 0; l < N; ++l) p[r][Sym<N>::at(l, l)] += 1.0;           // predict: P + Q, Q = I (experiment.py:167)
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc = fma(p[r][Sym<N>::at(l, j)], h[j], acc);
+                g[l] = acc;
+            }
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) a = fma(h[l], g[l], a);
+            double gamma;
+            if (fp.method == UVS_METHOD_GMCKF) {                                 // experiment.py:276-286
+                kap[r] = gaussian_kernel(nu[r], sigma);
+                const double r_hat = 1.0 / (kap[r] + fp.reg);
+                gamma = 1.0 / (a + r_hat);
+            } else if (fp.method == UVS_METHOD_IMCCKF) {                         // experiment.py:262-264
+                kap[r] = 1.0;
+                gamma = c_shared / (c_shared * a + 1.0);
+            } else {                                                             // KF, experiment.py:192
+                kap[r] = 1.0;
+                gamma = 1.0 / (a + 1.0);
+            }
+            const double step = gamma * nu[r];
+            const double beta = gamma * (2.0 - gamma * (a + 1.0));
+#pragma unroll
+            for (int l = 0; l < N; ++l) x[r][l] = fma(g[l], step, x[r][l]);      // X + K (Z - H X) (experiment.py:291)
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                const double w = beta * g[l];
+#pragma unroll
+                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = fma(-w, g[j], p[r][Sym<N>::at(l, j)]);
+            }
+        }
+    }
+
+    UVS_DEV int any_nonfinite() const {
+        int bad = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) bad |= !finite64(x[r][j]);
+        return group_or<L>(bad);
+    }
+};
+
+// ---------------------------------------------------------------- control law: dq = -gain * pinv(J) y
+// Overdetermined / square case (M >= N): Householder QR of [J | y] distributed over the L lanes of the
+// group (each lane holds R rows), then back substitution.  Equals numpy's pinv(J) @ y (experiment.py:312)
+// for full-column-rank J; exactly-zero columns give a zero component (pinv(0) = 0).
+template <int M, int N, int L>
+UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
+    constexpr int R = M / L;
+    double diag[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        constexpr int dummy = 0; (void)dummy;
+        const int owner = c / R, prow = c % R;                    // lane / local row holding global row c
+        double sig = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool below = (L == 1) ? (r > c) : (sub * R + r > c);
+            sig = below ? fma(a[r][c], a[r][c], sig) : sig;
+        }
+        sig = group_sum<L>(sig);
+        const double piv = group_pick<L>(a[prow][c], sub, owner);
+        const double nrm = sqrt(fma(piv, piv, sig));
+        const double alpha = (piv >= 0.0) ? -nrm : nrm;
+        const double vp = piv - alpha;                            // pivot entry of the Householder vector
+        const double denom = nrm * (nrm + fabs(piv));             // v.v / 2
+        const double tau = (denom > 0.0) ? 1.0 / denom : 0.0;
+        const bool mine = (L == 1) ? true : (sub == owner);
+#pragma unroll
+        for (int j = c + 1; j <= N; ++j) {
+            double d = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool below = (L == 1) ? (r > c) : (sub * R + r > c);
+                d = below ? fma(a[r][c], a[r][j], d) : d;
+            }
+            d = mine ? fma(vp, a[prow][j], d) : d;
+            d = group_sum<L>(d) * tau;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool below = (L == 1) ? (r > c) : (sub * R + r > c);
+                a[r][j] = below ? fma(-d, a[r][c], a[r][j]) : a[r][j];
+            }
+            a[prow][j] = mine ? fma(-d, vp, a[prow][j]) : a[prow][j];
+        }
+        diag[c] = (denom > 0.0) ? alpha : piv;                    // zero column below the pivot: R_cc = piv
+    }
+#pragma unroll
+    for (int c = N - 1; c >= 0; --c) {
+        const int owner = c / R, prow = c % R;
+        double rhs = a[prow][N];
+#pragma unroll
+        for (int j = c + 1; j < N; ++j) rhs = fma(-a[prow][j], sol[j], rhs);
+        rhs = group_pick<L>(rhs, sub, owner);
+        sol[c] = (diag[c] != 0.0) ? rhs / diag[c] : 0.0;
+    }
+}
+
+// Underdetermined case (M < N, e.g. one feature: 2 x 6): minimum-norm solution through the QR of J^T.
+// Only instantiated with L == 1 (the whole J in one lane).
+template <int M, int N>
+UVS_DEV void lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&sol)[N]) {
+    double b[N][M];                                               // J^T, overwritten by R (upper) and v (lower)
+    double vp[M], tau[M], diag[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) b[j][i] = J[i][j];
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+        double sig = 0.0;
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) sig = fma(b[r][c], b[r][c], sig);
+        const double piv = b[c][c];
+        const double nrm = sqrt(fma(piv, piv, sig));
+        const double alpha = (piv >= 0.0) ? -nrm : nrm;
+        const double denom = nrm * (nrm + fabs(piv));
+        vp[c] = piv - alpha;
+        tau[c] = (denom > 0.0) ? 1.0 / denom : 0.0;
+        diag[c] = (denom > 0.0) ? alpha : piv;
+#pragma unroll
+        for (int j = c + 1; j < M; ++j) {
+            double d = vp[c] * b[c][j];
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) d = fma(b[r][c], b[r][j], d);
+            d *= tau[c];
+            b[c][j] = fma(-d, vp[c], b[c][j]);
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) b[r][j] = fma(-d, b[r][c], b[r][j]);
+        }
+    }
+    // R^T w = y (forward substitution), then sol = Q [w; 0] = H_0 .. H_{M-1} [w; 0]
+    double w[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) w[j] = 0.0;
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+        double rhs = y[c];
+#pragma unroll
+        for (int j = 0; j < c; ++j) rhs = fma(-b[j][c], w[j], rhs);
+        w[c] = (diag[c] != 0.0) ? rhs / diag[c] : 0.0;
+    }
+#pragma unroll
+    for (int c = M - 1; c >= 0; --c) {
+        double d = vp[c] * w[c];
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) d = fma(b[r][c], w[r], d);
+        d *= tau[c];
+        w[c] = fma(-d, vp[c], w[c]);
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) w[r] = fma(-d, b[r][c], w[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) sol[j] = w[j];
+}
+
+// dq = -gain * pinv(X.reshape(m, n)) @ (kappa o err)   (experiment.py:300-312); result replicated in the group
+template <int M, int N, int L>
+UVS_DEV void control_law(const Rows<M, N, L> &st, const double (&kap)[M / L], const double (&err)[M / L], double gain, int sub,
+                         double (&dq)[N]) {
+    constexpr int R = M / L;
+    double sol[N];
+    if constexpr (M >= N) {
+        double a[R][N + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) a[r][j] = st.x[r][j];
+            a[r][N] = kap[r] * err[r];
+        }
+        lstsq_tall<M, N, L>(a, sub, sol);
+    } else {
+        static_assert(M >= N || L == 1, "wide Jacobians are handled one filter per lane");
+        double y[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) y[r] = kap[r] * err[r];
+        lstsq_wide<M, N>(st.x, y, sol);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) dq[j] = -gain * sol[j];
+}
+
+// ---------------------------------------------------------------- plant
+// Camera pose T_0_N of the DH chain at joints q: rot (row-major 3x3) and pos (ur10_simulation.py:97-110, 204-211).
+// When `zs`/`ps` are given they receive the z axis / origin of every intermediate frame for the Jacobian.
+template <int N, bool WITH_FRAMES>
+UVS_DEV void forward_kinematics(const uvs_plant &pl, const double (&q)[N], double (&rot)[9], double (&pos)[3],
+                                double (*zs)[3], double (*ps)[3]) {
+    double T[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s, c;
+        sincos(q[i] + pl.theta_offset[i], &s, &c);
+        const double ca = pl.cos_alpha[i], sa = pl.sin_alpha[i], aa = pl.a[i], dd = pl.d[i];
+        // link = Rz(theta) Tz(d) Rx(alpha) Tx(a)
+        const double l01 = -s * ca, l02 = s * sa, l03 = aa * c;
+        const double l11 = c * ca, l12 = -c * sa, l13 = aa * s;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double t0 = T[r][0], t1 = T[r][1], t2 = T[r][2], t3 = T[r][3];
+            T[r][0] = fma(t0, c, t1 * s);
+            T[r][1] = fma(t0, l01, fma(t1, l11, t2 * sa));
+            T[r][2] = fma(t0, l02, fma(t1, l12, t2 * ca));
+            T[r][3] = fma(t0, l03, fma(t1, l13, fma(t2, dd, t3)));
+        }
+        if constexpr (WITH_FRAMES) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { zs[i][r] = T[r][2]; ps[i][r] = T[r][3]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) rot[3 * r + cidx] = T[r][cidx];
+        pos[r] = T[r][3];
+    }
+}
+
+// Pinhole image coordinate `axis` (0 = u, 1 = v) of world point w seen from (rot, pos); depth = |pos - w| on request.
+UVS_DEV double project_axis(const double (&rot)[9], const double (&pos)[3], const double *w, int axis, double focal, double center) {
+    const double dx = w[0] - pos[0], dy = w[1] - pos[1], dz = w[2] - pos[2];
+    const double xc = fma(rot[0], dx, fma(rot[3], dy, rot[6] * dz));       // R^T (w - t)
+    const double yc = fma(rot[1], dx, fma(rot[4], dy, rot[7] * dz));
+    const double zc = fma(rot[2], dx, fma(rot[5], dy, rot[8] * dz));
+    return center + focal * (axis == 0 ? xc : yc) / zc;
+}
+
+// Noise-free features of this lane's R rows at joints q.
+template <int M, int N, int L>
+UVS_DEV void plant_features(const uvs_plant &pl, const double (&q)[N], int sub, double (&f)[M / L]) {
+    constexpr int R = M / L;
+    if (pl.kind == UVS_PLANT_LINEAR) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = sub * R + r;
+            double acc = pl.lin_f0[row];
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(pl.lin_jacobian[row * N + j], q[j] - pl.lin_q0[j], acc);
+            f[r] = acc;
+        }
+        return;
+    }
+    double rot[9], pos[3];
+    forward_kinematics<N, false>(pl, q, rot, pos, nullptr, nullptr);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = sub * R + r;
+        f[r] = project_axis(rot, pos, pl.points[row >> 1], row & 1, pl.focal, pl.center);
+    }
+}
+
+// Analytic initial guess X0 = J_img kron(I2, R^T) J_robot for this lane's rows, plus the noise-free f
+// at q (experiment.py:86-114; geometric Jacobian ur10_simulation.py:112-139).
+template <int M, int N, int L>
+UVS_DEV void initial_guess(const uvs_plant &pl, const double (&q)[N], int sub, double (&x)[M / L][N], double (&f)[M / L]) {
+    constexpr int R = M / L;
+    double rot[9], pos[3], zs[N][3], ps[N][3];
+    forward_kinematics<N, true>(pl, q, rot, pos, zs, ps);
+    double Jc[6][N];                                                        // camera-frame twist Jacobian kron(I2, R^T) J
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double z[3], o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            z[r] = (i == 0) ? (r == 2 ? 1.0 : 0.0) : zs[i - 1][r];
+            o[r] = (i == 0) ? 0.0 : ps[i - 1][r];
+        }
+        const double dx = pos[0] - o[0], dy = pos[1] - o[1], dz = pos[2] - o[2];
+        const double lin[3] = {z[1] * dz - z[2] * dy, z[2] * dx - z[0] * dz, z[0] * dy - z[1] * dx};   // z x (p_e - p)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Jc[r][i] = fma(rot[r], lin[0], fma(rot[3 + r], lin[1], rot[6 + r] * lin[2]));
+            Jc[3 + r][i] = fma(rot[r], z[0], fma(rot[3 + r], z[1], rot[6 + r] * z[2]));
+        }
+    }
+    const double F = pl.focal;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = sub * R + r;
+        const double *w = pl.points[row >> 1];
+        const double u = project_axis(rot, pos, w, 0, F, pl.center);
+        const double v = project_axis(rot, pos, w, 1, F, pl.center);
+        const double ddx = pos[0] - w[0], ddy = pos[1] - w[1], ddz = pos[2] - w[2];
+        const double depth = sqrt(fma(ddx, ddx, fma(ddy, ddy, ddz * ddz)));  // computeZ: |cam - disc|
+        double ji[6];
+        if ((row & 1) == 0) {                                                // experiment.py:101-109 (u row)
+            ji[0] = -F / depth; ji[1] = 0.0; ji[2] = u / depth; ji[3] = u * v / F; ji[4] = -(F * F + u * u) / F; ji[5] = v;
+            f[r] = u;
+        } else {                                                             // experiment.py:102-110 (v row)
+            ji[0] = 0.0; ji[1] = -F / depth; ji[2] = v / depth; ji[3] = (F * F + v * v) / F; ji[4] = -u * v / F; ji[5] = -u;
+            f[r] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc = fma(ji[k], Jc[k][j], acc);
+            x[r][j] = acc;
+        }
+    }
+}
+
+}  // namespace uvs

@@ -1,0 +1,171 @@
+"""Typed Python front of the C ABI: builds ``uvs_filter_params``, owns nothing but torch tensors on the GPU,
+and launches the HIP kernels on torch's current stream.  No numpy arithmetic of the estimator lives here --
+if the library or the GPU is missing these calls raise.
+
+Buffer layout.  Per-step streams are allocated *trial-fastest*: ``[step][component][trial]`` (``layout='kct'``).
+With one filter per lane (lanes_per_filter = 1) consecutive lanes then touch consecutive doubles, so every
+wavefront load/store of a stream component is one contiguous 512-byte segment.  ``layout='ktc'``
+(``[step][trial][component]``) suits the variants where several lanes share a filter; ``'tkc'`` is the
+reference's per-trial record order.  The kernels take strides, so all three work everywhere.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FilterParams, View, NULL_VIEW
+
+METHOD_CODES = {'KF': 2, 'MCKF': 3, 'IMCCKF': 4, 'GMCKF': 5}
+REG = 0.001 ** 2            # experiment.py:280
+ANNEAL_SPAN = 100.0         # experiment.py:271
+
+
+def loop_clock(t_s, t_max):
+    """Times at which the reference loop body runs: the clock starts at t_s (ur10_simulation.py:57) and advances by
+    t_s per iteration while t < t_max (experiment.py:125), accumulated in floating point exactly like the simulator stub."""
+    ts, t = [], 0.0 + t_s
+    while t < t_max:
+        ts.append(t)
+        t += t_s
+    return np.array(ts)
+
+
+def make_params(m, n, method='GMCKF', kernel_bw=10.0, annealing=False, t_s=0.05, t_max=15.0, gain=0.2, desired=None,
+                initial_guess=True, lanes=0, steps=None):
+    code = METHOD_CODES[method] if isinstance(method, str) else int(getattr(method, 'value', method))
+    fp = FilterParams()
+    fp.m, fp.n, fp.method, fp.annealing = m, n, code, int(bool(annealing))
+    fp.k_max = int(t_max / t_s)                                     # experiment.py:120
+    fp.steps = len(loop_clock(t_s, t_max)) if steps is None else int(steps)
+    fp.initial_guess, fp.lanes_per_filter = int(bool(initial_guess)), int(lanes)
+    fp.kernel_bw, fp.anneal_span, fp.gain, fp.dt, fp.reg = float(kernel_bw), ANNEAL_SPAN, float(gain), float(t_s), REG
+    if m > _lib.UVS_MAX_M or n > _lib.UVS_MAX_N:
+        raise ValueError('(m, n) exceeds UVS_MAX_M / UVS_MAX_N')
+    if desired is not None:
+        for i, v in enumerate(np.asarray(desired, float).ravel()):
+            fp.desired[i] = v
+    return fp
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.UvsLibraryError('no GPU visible: the RMCKF path runs only on the HIP library (no CPU fallback)')
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+_DIMS = {'kct': (2, 0, 1), 'ktc': (1, 0, 2), 'tkc': (0, 1, 2)}
+
+
+def alloc_stream(T, K, comp, layout='kct', device='cuda', zero=False):
+    """fp64 tensor for a [trial][step][comp] stream in the requested physical layout."""
+    torch = _torch()
+    shape = {'kct': (K, comp, T), 'ktc': (K, T, comp), 'tkc': (T, K, comp)}[layout]
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float64, device=device)
+
+
+def stream_view(tensor, layout='kct'):
+    return NULL_VIEW if tensor is None else _lib.view_of(tensor, _DIMS[layout])
+
+
+def as_tkc(tensor, layout='kct'):
+    """Logical [trial][step][comp] view (no copy) of a stream tensor."""
+    return tensor.permute({'kct': (2, 0, 1), 'ktc': (1, 0, 2), 'tkc': (0, 1, 2)}[layout])
+
+
+def supported_lanes(m, n):
+    buf = (C.c_int32 * 16)()
+    cnt = _lib.lib().uvs_supported_lanes(m, n, buf, 16)
+    return [buf[i] for i in range(min(cnt, 16))]
+
+
+def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False):
+    """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
+    ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``)."""
+    torch = _torch()
+    T, K, m, n = q_start.shape[0], fp.steps, fp.m, fp.n
+    dev = q_start.device
+    out = {}
+    for key, comp in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)):
+        out[key] = alloc_stream(T, K, comp, layout, dev, zero=True) if key in want else None
+    out['stats'] = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+    out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
+    out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
+    out['x_final'] = torch.empty((T, m * n), dtype=torch.float64, device=dev) if final_state else None
+    out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
+    flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
+    rc = _lib.lib().uvs_rmckf_closed_loop_f64(
+        C.byref(fp), C.byref(plant_struct), T, flat(q_start), stream_view(noise, layout), flat(x0),
+        stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['q'], layout),
+        stream_view(out['f'], layout), stream_view(out['dq'], layout),
+        out['stats'].data_ptr(), out['status'].data_ptr(), out['k_done'].data_ptr(),
+        flat(out['x_final']), flat(out['p_final']), _stream())
+    _lib.check(rc)
+    return out
+
+
+def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', final_state=False):
+    """Open-loop replay.  ``f``: stream tensor with K+1 steps, ``dq``: K steps, ``x0``: (T, m*n)."""
+    torch = _torch()
+    T, K, m, n = x0.shape[0], fp.steps, fp.m, fp.n
+    dev = x0.device
+    out = {}
+    for key, comp in (('x', m * n), ('err', m), ('kappa', m), ('dqcmd', n)):
+        out[key] = alloc_stream(T, K, comp, layout, dev, zero=True) if key in want else None
+    out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
+    out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
+    out['x_final'] = torch.empty((T, m * n), dtype=torch.float64, device=dev) if final_state else None
+    out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
+    flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
+    rc = _lib.lib().uvs_rmckf_replay_f64(
+        C.byref(fp), T, stream_view(f, layout), stream_view(dq, layout), flat(x0),
+        stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['kappa'], layout),
+        stream_view(out['dqcmd'], layout), out['status'].data_ptr(), out['k_done'].data_ptr(),
+        flat(out['x_final']), flat(out['p_final']), _stream())
+    _lib.check(rc)
+    return out
+
+
+class FilterBank:
+    """T estimators whose state (X, P) stays in HBM between ``step`` calls: the drop-in used when the robot is external."""
+
+    def __init__(self, fp, T=1, x0=None, device='cuda'):
+        torch = _torch()
+        self.fp, self.T = fp, T
+        m, n = fp.m, fp.n
+        self.X = torch.zeros((T, m * n), dtype=torch.float64, device=device)
+        if x0 is not None:
+            self.X.copy_(torch.as_tensor(np.asarray(x0, float).reshape(T, m * n)))
+        self.P = torch.eye(n, dtype=torch.float64, device=device).repeat(T, m, 1, 1).contiguous()   # P = I (experiment.py:73)
+        self.dq = torch.zeros((T, n), dtype=torch.float64, device=device)
+        self.err = torch.zeros((T, m), dtype=torch.float64, device=device)
+        self.kappa = torch.ones((T, m), dtype=torch.float64, device=device)
+        self.status = torch.zeros(T, dtype=torch.int32, device=device)
+        self.first = True
+
+    def step(self, f, f_old, dq_prev, k):
+        """f, f_old: (T, m), dq_prev: (T, n) cuda fp64 tensors.  Updates X, P in place; returns (dq, err, kappa, status)."""
+        f, f_old, dq_prev = f.contiguous(), f_old.contiguous(), dq_prev.contiguous()
+        rc = _lib.lib().uvs_rmckf_step_f64(C.byref(self.fp), self.T, self.X.data_ptr(), self.P.data_ptr(), f.data_ptr(),
+                                           f_old.data_ptr(), dq_prev.data_ptr(), int(self.first), int(k), self.dq.data_ptr(),
+                                           self.err.data_ptr(), self.kappa.data_ptr(), self.status.data_ptr(), _stream())
+        _lib.check(rc)
+        self.first = False
+        return self.dq, self.err, self.kappa, self.status
+
+
+def stats_reduce(err, t, k_done=None, layout='kct'):
+    """Per-trial ||ISE||, ||IAE||, ||ITAE|| (results/plot_errorbar.m:39-84) of an error stream tensor."""
+    torch = _torch()
+    e = as_tkc(err, layout)
+    T, K, m = e.shape
+    stats = torch.empty((T, 3), dtype=torch.float64, device=err.device)
+    t_dev = torch.as_tensor(np.asarray(t, float), device=err.device)
+    rc = _lib.lib().uvs_stats_reduce_f64(T, K, m, stream_view(err, layout), t_dev.data_ptr(),
+                                         None if k_done is None else k_done.data_ptr(), stats.data_ptr(), _stream())
+    _lib.check(rc)
+    return stats
