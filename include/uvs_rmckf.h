@@ -148,6 +148,12 @@ int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double
 int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const double *t, const int32_t *k_done,
                          double *stats, void *stream);
 
+/*
+ * Test hook: evaluates the library's fp64 helper functions on the device so that tests can bound their error against
+ * numpy.  which: 0 fast reciprocal, 1 sqrt, 2 rsqrt, 3 sin, 4 cos (bounded-argument sincos with library fallback), 5 exp.
+ */
+int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

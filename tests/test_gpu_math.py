@@ -1,0 +1,48 @@
+"""Device fp64 helper functions (csrc/rmckf_math.hpp) against numpy, through the uvs_debug_math_f64 test hook."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(which, x):
+    import torch
+    import uvs_amd
+    xd = torch.as_tensor(np.ascontiguousarray(x, float), device='cuda')
+    yd = torch.empty_like(xd)
+    rc = uvs_amd.lib().uvs_debug_math_f64(which, xd.numel(), xd.data_ptr(), yd.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    uvs_amd._lib.check(rc)
+    return yd.cpu().numpy()
+
+
+def _ulps(got, ref):
+    return np.abs(got - ref) / np.spacing(np.abs(ref))
+
+
+def test_fast_reciprocal_and_roots():
+    rng = np.random.default_rng(0)
+    x = np.exp(rng.uniform(np.log(1e-150), np.log(1e150), 200000)) * rng.choice([-1.0, 1.0], 200000)
+    assert _ulps(_eval(0, x), 1.0 / x).max() <= 1.5
+    xp = np.abs(x)
+    assert _ulps(_eval(1, xp), np.sqrt(xp)).max() <= 1.0
+    assert _ulps(_eval(2, xp), 1.0 / np.sqrt(xp)).max() <= 2.5
+
+
+def test_sincos_bounded_and_fallback():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-12, 12, 200000), rng.uniform(-1e5, 1e5, 100000), np.arange(-40, 41) * (np.pi / 2),
+                        np.arange(-40, 41) * (np.pi / 2) + 1e-9, [0.0, 1e-300, -1e-300, 1e-8], rng.uniform(-1e12, 1e12, 2000)])
+    s, c = _eval(3, x), _eval(4, x)
+    # absolute error relative to 1 (what the kinematics sees) and relative error away from the zeros
+    assert np.abs(s - np.sin(x)).max() <= 2.3e-16 and np.abs(c - np.cos(x)).max() <= 2.3e-16
+    big = np.abs(np.sin(x)) > 1e-3
+    assert _ulps(s[big], np.sin(x)[big]).max() <= 2.0
+    big = np.abs(np.cos(x)) > 1e-3
+    assert _ulps(c[big], np.cos(x)[big]).max() <= 2.0
+
+
+def test_exp_on_kernel_range():
+    x = -np.exp(np.random.default_rng(2).uniform(np.log(1e-12), np.log(700), 200000))
+    assert _ulps(_eval(5, x), np.exp(x)).max() <= 2.0

@@ -56,6 +56,7 @@ SYMBOLS = {
     'uvs_rmckf_replay_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 7 + [_VP] * 2 + [View] * 2 + [_VP]),
     'uvs_rmckf_step_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [_VP] * 5 + [_I32, _I32] + [_VP] * 4 + [_VP]),
     'uvs_stats_reduce_f64': (C.c_int, [_I64, _I32, _I32, View, _VP, _VP, _VP, _VP]),
+    'uvs_debug_math_f64': (C.c_int, [_I32, _I64, _VP, _VP, _VP]),
 }
 
 _lib = None
@@ -77,6 +78,10 @@ def lib():
             raise UvsLibraryError(f'{LIB_PATH} is missing: run `make -C {CSRC}` (or __graft_entry__.build()); '
                                   'there is no CPU fallback for the RMCKF path')
         try:
+            # One HIP runtime per process: PyTorch bundles its own libamdhip64 (soname libamdhip64.so.7).  Loading it first makes
+            # our DT_NEEDED libamdhip64.so.7 resolve to that same instance, so torch tensors, streams and our kernels share one
+            # runtime; the other order loads /opt/rocm's copy as a second runtime that sees no device.
+            import torch  # noqa: F401
             handle = C.CDLL(LIB_PATH)
         except OSError as exc:
             raise UvsLibraryError(f'cannot load {LIB_PATH}: {exc}') from exc

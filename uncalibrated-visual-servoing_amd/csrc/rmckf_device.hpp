@@ -52,6 +52,33 @@ struct View {
 };
 static inline View to_view(const uvs_view &v) { return View{v.base, v.trial_stride, v.step_stride, v.comp_stride}; }
 
+// ---------------------------------------------------------------- kernel argument blocks (passed by value)
+struct ClosedArgs {
+    uvs_filter_params fp;
+    uvs_plant plant;
+    long long T;
+    View q_start, noise, x0, x_out, err_out, q_out, f_out, dq_out, x_final, p_final;
+    double *stats;
+    int *status, *k_done;
+};
+
+struct ReplayArgs {
+    uvs_filter_params fp;
+    long long T;
+    View f, dq, x0, x_out, err_out, kappa_out, dqcmd_out, x_final, p_final;
+    int *status, *k_done;
+};
+
+struct StepArgs {
+    uvs_filter_params fp;
+    long long T;
+    double *X, *P;
+    const double *f, *f_old, *dq_prev;
+    int first, k;
+    double *dq_out, *err_out, *kappa_out;
+    int *status;
+};
+
 // ---------------------------------------------------------------- packed symmetric n x n
 template <int N>
 struct Sym {

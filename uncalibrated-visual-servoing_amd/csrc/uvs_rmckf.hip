@@ -11,34 +11,9 @@
 #include <cstdio>
 #include <cstring>
 #include "rmckf_device.hpp"
+#include "rmckf_l1.hpp"
 
 namespace uvs {
-
-struct ClosedArgs {
-    uvs_filter_params fp;
-    uvs_plant plant;
-    long long T;
-    View q_start, noise, x0, x_out, err_out, q_out, f_out, dq_out, x_final, p_final;
-    double *stats;
-    int *status, *k_done;
-};
-
-struct ReplayArgs {
-    uvs_filter_params fp;
-    long long T;
-    View f, dq, x0, x_out, err_out, kappa_out, dqcmd_out, x_final, p_final;
-    int *status, *k_done;
-};
-
-struct StepArgs {
-    uvs_filter_params fp;
-    long long T;
-    double *X, *P;
-    const double *f, *f_old, *dq_prev;
-    int first, k;
-    double *dq_out, *err_out, *kappa_out;
-    int *status;
-};
 
 template <int M, int N, int L>
 UVS_DEV void store_final(const Rows<M, N, L> &st, const View &xf, const View &pf, long long trial, int sub) {
@@ -320,6 +295,22 @@ __global__ __launch_bounds__(256) void stats_kernel(long long T, int K, int m, V
     stats[3 * trial + 2] = sqrt(n_itae);
 }
 
+// ------------------------------------------------------------------------------------------------ math self-test
+__global__ __launch_bounds__(256) void debug_math_kernel(int which, long long n, const double *x, double *y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double s, c, r;
+    switch (which) {
+        case 0: y[i] = fast_rcp(v); break;
+        case 1: fast_sqrt_rsqrt(v, s, r); y[i] = s; break;
+        case 2: fast_sqrt_rsqrt(v, s, r); y[i] = r; break;
+        case 3: sincos_any(v, s, c); y[i] = s; break;
+        case 4: sincos_any(v, s, c); y[i] = c; break;
+        default: y[i] = exp(v); break;
+    }
+}
+
 }  // namespace uvs
 
 // ================================================================================================ C ABI
@@ -348,6 +339,8 @@ int check_launch(const char *what) {
     X(6, 6, 1) \
     X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)
 
+#define UVS_TUNED_SHAPES(X) X(8, 6) X(6, 6)
+
 int default_lanes(int m, int n) {
 #define X(M, N, L) if (m == M && n == N) return L;
     UVS_SHAPES(X)
@@ -361,7 +354,7 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
     if (fp->steps < 0 || fp->k_max <= 0) return fail(UVS_ERR_ARG, "%s", "steps must be >= 0 and k_max > 0");
     if (fp->method != UVS_METHOD_KF && fp->method != UVS_METHOD_IMCCKF && fp->method != UVS_METHOD_GMCKF)
         return fail(UVS_ERR_METHOD, "%s", "method must be KF, IMCCKF or GMCKF on the HIP path");
-    const int L = fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n);
+    const int L = fp->lanes_per_filter == -1 ? 1 : (fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n));
     if (L == 0) return fail(UVS_ERR_SHAPE, "%s", "(m, n) is not instantiated in libuvs_rmckf");
     *lanes = L;
     return UVS_OK;
@@ -411,6 +404,20 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     A.stats = stats; A.status = status; A.k_done = k_done;
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
+    // lanes_per_filter == 1 selects the tuned one-filter-per-lane kernel (rmckf_l1.hpp) where it exists; -1 forces the
+    // generic template at one lane per filter (kept as an in-library cross-check of the tuned code).
+    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF) && fp->lanes_per_filter != -1;
+#define XT(M, N) \
+    if (!launched && tuned_ok && L == 1 && fp->m == M && fp->n == N) { \
+        const bool gm = fp->method == UVS_METHOD_GMCKF, lin = plant->kind == UVS_PLANT_LINEAR; \
+        if (gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>), grid_for(T, 1), dim3(64), 0, s, A); \
+        if (gm && lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>), grid_for(T, 1), dim3(64), 0, s, A); \
+        if (!gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>), grid_for(T, 1), dim3(64), 0, s, A); \
+        if (!gm && lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_KF, UVS_PLANT_LINEAR>), grid_for(T, 1), dim3(64), 0, s, A); \
+        launched = true; \
+    }
+    UVS_TUNED_SHAPES(XT)
+#undef XT
 #define X(M, N, LL) \
     if (!launched && fp->m == M && fp->n == N && L == LL) { \
         hipLaunchKernelGGL((uvs::closed_loop_kernel<M, N, LL>), grid_for(T, LL), dim3(64), 0, s, A); \
@@ -475,6 +482,12 @@ int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const do
     hipLaunchKernelGGL(uvs::stats_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)T, K, m,
                        uvs::to_view(err), t, k_done, stats);
     return check_launch("stats_kernel");
+}
+
+int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
+    if (n <= 0 || !x || !y) return fail(UVS_ERR_ARG, "%s", "bad debug_math arguments");
+    hipLaunchKernelGGL(uvs::debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, (long long)n, x, y);
+    return check_launch("debug_math_kernel");
 }
 
 }  // extern "C"
