@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 CLOSED = [n for n in golden_names('closed_') if '_mckf_' not in n]          # KF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
-LANES_86 = (1, -1, 2, 4, 8)              # 1 = tuned one-filter-per-lane kernel, -1 = generic template at one lane
+LANES_86 = (1, 2, -1, -2, 4, 8)          # 1, 2: tuned kernel (closed loop); negative: generic template with |L| lanes
 
 
 @pytest.fixture(scope='module')

@@ -11,7 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include "rmckf_device.hpp"
-#include "rmckf_l1.hpp"
+#include "rmckf_tuned.hpp"
 
 namespace uvs {
 
@@ -336,10 +336,10 @@ int check_launch(const char *what) {
 #define UVS_SHAPES(X) \
     X(8, 6, 1) X(8, 6, 2) X(8, 6, 4) X(8, 6, 8) \
     X(2, 6, 1) \
-    X(6, 6, 1) \
+    X(6, 6, 1) X(6, 6, 2) \
     X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)
 
-#define UVS_TUNED_SHAPES(X) X(8, 6) X(6, 6)
+#define UVS_TUNED_SHAPES(X) X(8, 6, 1) X(8, 6, 2) X(6, 6, 1) X(6, 6, 2)
 
 int default_lanes(int m, int n) {
 #define X(M, N, L) if (m == M && n == N) return L;
@@ -354,7 +354,7 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
     if (fp->steps < 0 || fp->k_max <= 0) return fail(UVS_ERR_ARG, "%s", "steps must be >= 0 and k_max > 0");
     if (fp->method != UVS_METHOD_KF && fp->method != UVS_METHOD_IMCCKF && fp->method != UVS_METHOD_GMCKF)
         return fail(UVS_ERR_METHOD, "%s", "method must be KF, IMCCKF or GMCKF on the HIP path");
-    const int L = fp->lanes_per_filter == -1 ? 1 : (fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n));
+    const int L = fp->lanes_per_filter < 0 ? -fp->lanes_per_filter : (fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n));
     if (L == 0) return fail(UVS_ERR_SHAPE, "%s", "(m, n) is not instantiated in libuvs_rmckf");
     *lanes = L;
     return UVS_OK;
@@ -404,16 +404,16 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     A.stats = stats; A.status = status; A.k_done = k_done;
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
-    // lanes_per_filter == 1 selects the tuned one-filter-per-lane kernel (rmckf_l1.hpp) where it exists; -1 forces the
-    // generic template at one lane per filter (kept as an in-library cross-check of the tuned code).
-    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF) && fp->lanes_per_filter != -1;
-#define XT(M, N) \
-    if (!launched && tuned_ok && L == 1 && fp->m == M && fp->n == N) { \
+    // lanes_per_filter 1 / 2 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic
+    // template with |value| lanes (kept as an in-library cross-check of the tuned code).
+    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF) && fp->lanes_per_filter >= 0;
+#define XT(M, N, LL) \
+    if (!launched && tuned_ok && L == LL && fp->m == M && fp->n == N) { \
         const bool gm = fp->method == UVS_METHOD_GMCKF, lin = plant->kind == UVS_PLANT_LINEAR; \
-        if (gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>), grid_for(T, 1), dim3(64), 0, s, A); \
-        if (gm && lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>), grid_for(T, 1), dim3(64), 0, s, A); \
-        if (!gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>), grid_for(T, 1), dim3(64), 0, s, A); \
-        if (!gm && lin) hipLaunchKernelGGL((uvs::closed_loop_l1_kernel<M, N, UVS_METHOD_KF, UVS_PLANT_LINEAR>), grid_for(T, 1), dim3(64), 0, s, A); \
+        if (gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>), grid_for(T, LL), dim3(64), 0, s, A); \
+        if (gm && lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>), grid_for(T, LL), dim3(64), 0, s, A); \
+        if (!gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>), grid_for(T, LL), dim3(64), 0, s, A); \
+        if (!gm && lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_KF, UVS_PLANT_LINEAR>), grid_for(T, LL), dim3(64), 0, s, A); \
         launched = true; \
     }
     UVS_TUNED_SHAPES(XT)
