@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 CLOSED = [n for n in golden_names('closed_') if '_mckf_' not in n]          # KF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
-LANES_86 = (1, 2, -1, -2, 4, 8)          # 1, 2: tuned kernel (closed loop); negative: generic template with |L| lanes
+LANES_86 = (1, 2, 4, -1, -2, -4, 8)      # 1, 2, 4: tuned kernel (closed loop); negative: generic template with |L| lanes
 
 
 @pytest.fixture(scope='module')
@@ -203,7 +203,7 @@ def test_non_finite_state_fails_the_trial_only(uvs):
     assert list(status) == [0, 0, 1, 0, 0, 0] and k_done[2] == bad_step and np.all(np.delete(k_done, 2) == K)
     err = out['err'].cpu().numpy()
     assert np.array_equal(err[:, :, 0], err[:, :, 5]) and rel_err(err[:, :, 0], g['err'][:K]) <= 1e-8
-    assert np.array_equal(err[:bad_step, :, 2], err[:bad_step, :, 0]) and np.all(err[bad_step:, :, 2] == 0)
+    assert np.array_equal(err[:bad_step, :, 2], err[:bad_step, :, 0])      # rows >= k_done are unspecified (the reference trims them)
 
 
 # ---------------------------------------------------------------------------------------------- statistics kernel

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Run BASELINE config 2 once on the -DUVS_STAMPS build and print the per-phase cycle shares of the tuned kernel.
+usage (GPU box): UVS_LIB_PATH=<pkg>/libuvs_stamps.so python tools/read_stamps.py [lanes]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import uvs_amd  # noqa: E402
+import bench  # noqa: E402
+
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+T, K = 65536, 299
+cfg = bench.config2()
+plan = uvs_amd.batch.plan_trials(cfg, cells=[1.5])
+fp = uvs_amd.engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, lanes)
+noise = torch.empty((K, 8, T), dtype=torch.float64, device='cuda').normal_()
+q0 = torch.as_tensor(plan.q_start, device='cuda')
+plant = uvs_amd.SyntheticPlant.ur10().to_struct()
+for _ in range(2):
+    out = uvs_amd.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+torch.cuda.synchronize()
+stats = out['stats'].cpu().numpy().ravel()
+tpw = 64 // lanes
+waves = T // tpw
+st = np.stack([stats[3 * w * tpw: 3 * w * tpw + 6] for w in range(waves)])
+names = ['noise-issue + plant', 'row updates', 'control law (QR)', 'logs + stats', '(unused)', 'loop edge']
+tot = st.sum(axis=1)
+print(f'waves {waves}, cycles per wave: mean {tot.mean():.0f}  min {tot.min():.0f}  max {tot.max():.0f};  per step {tot.mean() / K:.0f}')
+for i, n in enumerate(names):
+    print(f'  {n:24s} {st[:, i].mean() / K:9.0f} cycles/step  {100 * st[:, i].mean() / tot.mean():5.1f}%')

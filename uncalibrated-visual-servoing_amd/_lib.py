@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libuvs_rmckf.so')
+LIB_PATH = os.environ.get('UVS_LIB_PATH', os.path.join(HERE, 'libuvs_rmckf.so'))   # override only for diagnostic builds
 CSRC = os.path.join(HERE, 'csrc')
 
 UVS_MAX_M, UVS_MAX_N, UVS_MAX_POINTS = 32, 8, 16

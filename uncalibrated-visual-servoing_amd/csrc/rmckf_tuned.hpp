@@ -17,6 +17,22 @@
 
 namespace uvs {
 
+// Diagnostic build -DUVS_STAMPS: per-phase cycle sums (s_memtime) of every wavefront, written over the first words of that
+// wavefront's slice of `stats` (which is therefore garbage in this build).  Never used in the shipped library.
+#ifdef UVS_STAMPS
+#define UVS_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        stamp_sum[slot] += now_ - stamp_last;                                             \
+        stamp_last = now_;                                                                \
+    } while (0)
+#else
+#define UVS_STAMP(slot) do { } while (0)
+#endif
+
 // DPP quad_perm move of a double (two 32-bit moves).  CTRL = a | b<<2 | c<<4 | d<<6 selects the source lane of each lane of a quad.
 template <int CTRL>
 UVS_DEV double dpp_quad(double v) {
@@ -29,60 +45,39 @@ constexpr int kSwapPair = 0xB1;      // quad_perm [1,0,3,2]: partner lane
 constexpr int kFromEven = 0xA0;      // quad_perm [0,0,2,2]: value of the pair's even lane
 constexpr int kFromOdd = 0xF5;       // quad_perm [1,1,3,3]: value of the pair's odd lane
 
+constexpr int kSwapHalf = 0x4E;      // quad_perm [2,3,0,1]: the other pair of the quad
+
+// Sum over the L (1, 2 or 4) lanes of a filter; every lane gets the bit-identical total.
 template <int L>
 UVS_DEV double pair_sum(double v) {
     if constexpr (L == 1) return v;
-    return v + dpp_quad<kSwapPair>(v);
+    v += dpp_quad<kSwapPair>(v);
+    if constexpr (L == 4) v += dpp_quad<kSwapHalf>(v);
+    return v;
 }
+// Value held by lane OWNER of the group, delivered to all its lanes.
 template <int L, int OWNER>
 UVS_DEV double pair_from(double v) {
     if constexpr (L == 1) return v;
-    return OWNER ? dpp_quad<kFromOdd>(v) : dpp_quad<kFromEven>(v);
+    if constexpr (L == 2) return OWNER ? dpp_quad<kFromOdd>(v) : dpp_quad<kFromEven>(v);
+    return dpp_quad<OWNER * 0x55>(v);                   // quad_perm [o,o,o,o]
 }
-
-// Uniform (per-wavefront) base + 32-bit per-lane element offset.
-struct LaneStream {
-    double *base;          // view base + first_trial_of_wave * trial_stride   (uniform)
-    long long sk, sc;      // step / component strides                          (uniform)
-    bool on;
-    UVS_DEV double *row(int k) const { return base + (long long)k * sk; }
-};
-UVS_DEV LaneStream lane_stream(const View &v, long long wave_first_trial) {
-    return LaneStream{v.p + wave_first_trial * v.st, v.sk, v.sc, v.p != nullptr};
+template <int L>
+UVS_DEV double pair_from_dyn(double v, int owner) {      // owner is a compile-time constant after unrolling
+    if constexpr (L == 1) return v;
+    switch (owner) {
+        case 0: return pair_from<L, 0>(v);
+        case 1: return pair_from<L, 1>(v);
+        case 2: return pair_from<L, (L > 2 ? 2 : 0)>(v);
+        default: return pair_from<L, (L > 2 ? 3 : 0)>(v);
+    }
 }
-
-// Camera pose with the fast bounded-argument sincos (same arithmetic as forward_kinematics<N,false> otherwise).
-template <int N>
-UVS_DEV void camera_pose_fast(const uvs_plant &pl, const double (&q)[N], double (&rot)[9], double (&pos)[3]) {
-    double T[3][4];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double s, c;
-        sincos_any(q[i] + pl.theta_offset[i], s, c);
-        const double ca = pl.cos_alpha[i], sa = pl.sin_alpha[i], aa = pl.a[i], dd = pl.d[i];
-        const double l01 = -s * ca, l02 = s * sa, l03 = aa * c;
-        const double l11 = c * ca, l12 = -c * sa, l13 = aa * s;
-        if (i == 0) {                               // T_0_1 is the first link itself
-            T[0][0] = c; T[0][1] = l01; T[0][2] = l02; T[0][3] = l03;
-            T[1][0] = s; T[1][1] = l11; T[1][2] = l12; T[1][3] = l13;
-            T[2][0] = 0.0; T[2][1] = sa; T[2][2] = ca; T[2][3] = dd;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double t0 = T[r][0], t1 = T[r][1], t2 = T[r][2], t3 = T[r][3];
-                T[r][0] = fma(t0, c, t1 * s);
-                T[r][1] = fma(t0, l01, fma(t1, l11, t2 * sa));
-                T[r][2] = fma(t0, l02, fma(t1, l12, t2 * ca));
-                T[r][3] = fma(t0, l03, fma(t1, l13, fma(t2, dd, t3)));
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int cidx = 0; cidx < 3; ++cidx) rot[3 * r + cidx] = T[r][cidx];
-        pos[r] = T[r][3];
-    }
+// Per-lane choice among the L values v[0..L) by the lane's position in its group.
+template <int L>
+UVS_DEV double pick_sub(const double *v, int sub) {
+    if constexpr (L == 1) return v[0];
+    if constexpr (L == 2) return sub ? v[1] : v[0];
+    return (sub & 2) ? ((sub & 1) ? v[3] : v[2]) : ((sub & 1) ? v[1] : v[0]);
 }
 
 // Householder QR least squares, rows interleaved over the L lanes of a filter: local row r of lane s is global row r*L + s.
@@ -103,7 +98,7 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
 #pragma unroll
         for (int r = m + 1; r < R; ++r) sig = fma(a[r][c], a[r][c], sig);
         sig = pair_sum<L>(sig);
-        const double piv = (owner == 0) ? pair_from<L, 0>(a[m][c]) : pair_from<L, 1>(a[m][c]);
+        const double piv = pair_from_dyn<L>(a[m][c], owner);
         const double n2 = fma(piv, piv, sig);
         double nrm, rn;
         fast_sqrt_rsqrt(n2, nrm, rn);
@@ -130,66 +125,130 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         double rhs = a[m][N];
 #pragma unroll
         for (int j = c + 1; j < N; ++j) rhs = fma(-a[m][j], sol[j], rhs);
-        rhs = (owner == 0) ? pair_from<L, 0>(rhs) : pair_from<L, 1>(rhs);
+        rhs = pair_from_dyn<L>(rhs, owner);
         sol[c] = rhs * rdiag[c];
     }
 }
 
-template <int M, int N, int L, int METHOD, int PLANT>
-__global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs A) {
-    static_assert(M >= N && (L == 1 || L == 2) && M % L == 0, "tuned kernel: tall Jacobian, 1 or 2 lanes per filter");
+// Plant constants are broadcast from LDS (one ds_read per pair of doubles) instead of sitting in ~90 SGPRs that the register
+// allocator would spill to VGPR lanes and fetch back with v_readlane + s_nop on every use.
+template <int M, int N>
+struct PlantLds {
+    static constexpr int kJoint = 0;                   // 5 doubles per joint: theta_offset, d, a, cos_alpha, sin_alpha
+    static constexpr int kPoint = 5 * N;               // 3 doubles per point
+    static constexpr int kCam = kPoint + 3 * (M / 2);  // focal, center
+    static constexpr int kCount = kCam + 2;
+};
+
+// PV = number of this lane's covariance blocks kept in VGPRs; the other R - PV blocks live in LDS and pass through registers
+// only while their row is updated (an LDS round trip moves two doubles per instruction, an AGPR one half a double).
+// XOUT = write the per-step X stream.
+//
+// Store discipline: the step body is straight-line code.  Lanes of a padding trial shadow the last real trial (same inputs,
+// same values, same addresses: their stores are duplicates), both lanes of a pair store the replicated q / dq, and a trial
+// that FAILs keeps running on NaNs -- rows at and after its k_done are unspecified, exactly the rows the reference trims
+// (experiment.py:345-352).
+// With L = 4 the whole state fits the 256 VALU-addressable registers (P: 84, X: 24), LDS holds only the statistics and
+// the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
+// issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
+template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
+__global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
+    static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
+    constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
+    // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
+    // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
+    constexpr bool SPLIT = (PLANT == UVS_PLANT_DH_PINHOLE) && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
+    constexpr int G = SPLIT ? (L == 2 ? 2 : 3) : 1;
+    constexpr int JG = N / G;                                      // joints tracked by this lane
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;       // rows per lane, packed block size, trials per wavefront
-    __shared__ double lds_x[R * N][64];
+    static_assert(PV >= 0 && PV <= R, "PV counts covariance blocks");
+    constexpr int PL = R - PV;                                     // blocks resident in LDS
+    using PC = PlantLds<M, N>;
+    __shared__ double lds_x[XREG ? 1 : R * N][64];
     __shared__ double lds_acc[3 * R][64];
+    __shared__ double lds_p[PL > 0 ? PL * NP : 1][64];
+    __shared__ double lds_c[PC::kCount];
 
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
+    const int grp = SPLIT ? (sub < G ? sub : G - 1) : 0;           // with L = 4 the fourth lane mirrors group 2
     const long long wave_first = (long long)blockIdx.x * TPW;      // first trial of this wavefront (uniform)
     const unsigned tl = lane / L;                                   // trial within the wavefront
     const bool valid = wave_first + tl < A.T;
-    const unsigned tq = valid ? tl : (unsigned)(A.T - 1 - wave_first);   // padding lanes shadow the last trial
+    const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
 
-    const LaneStream s_noise = lane_stream(A.noise, wave_first), s_x = lane_stream(A.x_out, wave_first),
-                     s_err = lane_stream(A.err_out, wave_first), s_q = lane_stream(A.q_out, wave_first),
-                     s_f = lane_stream(A.f_out, wave_first), s_dq = lane_stream(A.dq_out, wave_first);
-    // per-lane element offsets: trial * trial_stride + (first owned row) * component stride
-    const unsigned lo_noise = tq * (unsigned)A.noise.st + sub * (unsigned)A.noise.sc;
-    const unsigned lo_err = tq * (unsigned)A.err_out.st + sub * (unsigned)A.err_out.sc;
-    const unsigned lo_f = tq * (unsigned)A.f_out.st + sub * (unsigned)A.f_out.sc;
-    const unsigned lo_x = tq * (unsigned)A.x_out.st + sub * N * (unsigned)A.x_out.sc;
-    const unsigned lo_q = tq * (unsigned)A.q_out.st, lo_dq = tq * (unsigned)A.dq_out.st;
+    // per-lane stream cursors (advance by the step stride once per step; components are reached by adding the uniform stride)
+    const double *pn = A.noise.p ? A.noise.at(trial, 0, sub) : nullptr;
+    double *px = A.x_out.p ? A.x_out.at(trial, 0, sub * N) : nullptr;
+    double *pe = A.err_out.p ? A.err_out.at(trial, 0, sub) : nullptr;
+    double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
+    double *pq = A.q_out.p ? A.q_out.at(trial, 0, grp * JG) : nullptr;
+    double *pd = A.dq_out.p ? A.dq_out.at(trial, 0, grp * JG) : nullptr;
+    const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
+               on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
 
-    double q[N], dq[N], f_prev[R], des[R];
-    double p[R][NP];
-    {
+    if constexpr (PLANT == UVS_PLANT_DH_PINHOLE) {
+        if (lane < N) {
+            lds_c[PC::kJoint + 5 * lane + 0] = A.plant.theta_offset[lane];
+            lds_c[PC::kJoint + 5 * lane + 1] = A.plant.d[lane];
+            lds_c[PC::kJoint + 5 * lane + 2] = A.plant.a[lane];
+            lds_c[PC::kJoint + 5 * lane + 3] = A.plant.cos_alpha[lane];
+            lds_c[PC::kJoint + 5 * lane + 4] = A.plant.sin_alpha[lane];
+        }
+        if (lane < M / 2) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) { q[j] = *A.q_start.at(wave_first + tq, 0, j); dq[j] = 0.0; }
+            for (int c = 0; c < 3; ++c) lds_c[PC::kPoint + 3 * lane + c] = A.plant.points[lane][c];
+        }
+        if (lane == 0) { lds_c[PC::kCam] = A.plant.focal; lds_c[PC::kCam + 1] = A.plant.center; }
+    }
+
+    double q[JG], dq[N], f_prev[R], des[R];                        // q: this lane's joints; dq: replicated command
+    double p[PV > 0 ? PV : 1][NP];
+    double xr[XREG ? R : 1][N];                                    // X when it lives in registers
+    {
+        double q_all[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { q_all[j] = *A.q_start.at(trial, 0, j); dq[j] = 0.0; }
+#pragma unroll
+        for (int u = 0; u < JG; ++u) {
+            double cand[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cand[g] = q_all[g * JG + u];
+            q[u] = (G == 1) ? cand[0] : (G == 2 ? (grp ? cand[1] : cand[0]) : (grp == 0 ? cand[0] : (grp == 1 ? cand[1] : cand[G - 1])));
+        }
         double x0[R][N];
         if (fp.initial_guess) {
-            // generic helper owns rows sub*R .. ; here rows are interleaved, so evaluate row by row
-            double xa[M][N], fa[M];
-            initial_guess<M, N, 1>(A.plant, q, 0, xa, fa);
+            double xa[M][N], fa[M];                                // all rows, then keep this lane's interleaved share
+            initial_guess<M, N, 1>(A.plant, q_all, 0, xa, fa);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                f_prev[r] = (L == 1) ? fa[r] : (sub ? fa[r * L + 1] : fa[r * L]);
+                f_prev[r] = pick_sub<L>(&fa[r * L], sub);
 #pragma unroll
-                for (int j = 0; j < N; ++j) x0[r][j] = (L == 1) ? xa[r][j] : (sub ? xa[r * L + 1][j] : xa[r * L][j]);
+                for (int j = 0; j < N; ++j) {
+                    double cand[L];
+#pragma unroll
+                    for (int u = 0; u < L; ++u) cand[u] = xa[r * L + u][j];
+                    x0[r][j] = pick_sub<L>(cand, sub);
+                }
             }
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                f_prev[r] = 0.0;
+                f_prev[r] = 0.0;                                   // f = zeros(m) (experiment.py:56)
 #pragma unroll
-                for (int j = 0; j < N; ++j) x0[r][j] = *A.x0.at(wave_first + tq, 0, (r * L + sub) * N + j);
+                for (int j = 0; j < N; ++j) x0[r][j] = *A.x0.at(trial, 0, (r * L + sub) * N + j);
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            des[r] = (L == 1) ? fp.desired[r] : (sub ? fp.desired[r * L + 1] : fp.desired[r * L]);
+            des[r] = pick_sub<L>(&fp.desired[r * L], sub);
 #pragma unroll
-            for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x0[r][j];
+            for (int j = 0; j < N; ++j) {
+                if constexpr (XREG) xr[r][j] = x0[r][j];
+                else lds_x[r * N + j][lane] = x0[r][j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3 * R; ++i) lds_acc[i][lane] = 0.0;
@@ -198,24 +257,46 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
 #pragma unroll
             for (int l = 0; l < N; ++l)
 #pragma unroll
-                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = (l == j) ? 1.0 : 0.0;
+                for (int j = l; j < N; ++j) {
+                    const double v = (l == j) ? 1.0 : 0.0;                     // P = I (experiment.py:73)
+                    if (r < PV) p[r < PV ? r : 0][Sym<N>::at(l, j)] = v;
+                    else lds_p[(r - PV) * NP + Sym<N>::at(l, j)][lane] = v;
+                }
     }
+    __syncthreads();                                               // lds_c is read by every lane
 
     double t = fp.dt;
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true;
+#ifdef UVS_STAMPS
+    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
     for (int k = 0; k < K; ++k) {
+        asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
+        UVS_STAMP(5);
         // ---- noise load first (its latency hides under the kinematics)
         double nz[R];
-        {
-            double *nb = s_noise.row(k);
+        if (on_noise) {
+            const double *pr = pn;
 #pragma unroll
-            for (int r = 0; r < R; ++r) nz[r] = s_noise.on ? (nb + r * L * s_noise.sc)[lo_noise] : 0.0;
+            for (int r = 0; r < R; ++r) { nz[r] = *pr; pr += L * A.noise.sc; }
+            pn += A.noise.sk;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) nz[r] = 0.0;
         }
         // ---- plant: noise-free features of this lane's rows
         double z[R];
+#ifdef UVS_ABLATE_PLANT           // diagnostic build: cheap stand-in that keeps the dependence on q
+#pragma unroll
+        for (int r = 0; r < R; ++r) z[r] = fma(q[r % JG], 100.0, 128.0);
+        if constexpr (true) {
+        } else if constexpr (PLANT == UVS_PLANT_LINEAR) {
+#else
         if constexpr (PLANT == UVS_PLANT_LINEAR) {
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = r * L + sub;
@@ -225,64 +306,151 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
                 z[r] = acc;
             }
         } else {
-            double rot[9], pos[3];
-            camera_pose_fast<N>(A.plant, q, rot, pos);
+            // joint angles of this lane's links; one range test per step decides between the bounded sincos and the library routine
+            const double *cj = &lds_c[PC::kJoint + 5 * JG * grp];
+            double th[JG], sn[JG], cs[JG];
+            bool big = false;
+#pragma unroll
+            for (int u = 0; u < JG; ++u) {
+                th[u] = q[u] + cj[5 * u];
+                big |= !(fabs(th[u]) <= kSinCosBoundedMax);
+            }
+            if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+                for (int u = 0; u < JG; ++u) sincos(th[u], &sn[u], &cs[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < JG; ++u) sincos_bounded(th[u], sn[u], cs[u]);
+            }
+            double T[3][4];                                 // product of this lane's links (the whole chain when !SPLIT)
+#pragma unroll
+            for (int u = 0; u < JG; ++u) {
+                const double s = sn[u], c = cs[u];
+                const double dd = cj[5 * u + 1], aa = cj[5 * u + 2], ca = cj[5 * u + 3], sa = cj[5 * u + 4];
+                const double l01 = -s * ca, l02 = s * sa, l03 = aa * c;
+                const double l11 = c * ca, l12 = -c * sa, l13 = aa * s;
+                if (u == 0) {                           // link = Rz(theta) Tz(d) Rx(alpha) Tx(a) (ur10_simulation.py:204-211)
+                    T[0][0] = c; T[0][1] = l01; T[0][2] = l02; T[0][3] = l03;
+                    T[1][0] = s; T[1][1] = l11; T[1][2] = l12; T[1][3] = l13;
+                    T[2][0] = 0.0; T[2][1] = sa; T[2][2] = ca; T[2][3] = dd;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double t0 = T[r][0], t1 = T[r][1], t2 = T[r][2], t3 = T[r][3];
+                        T[r][0] = fma(t0, c, t1 * s);
+                        T[r][1] = fma(t0, l01, fma(t1, l11, t2 * sa));
+                        T[r][2] = fma(t0, l02, fma(t1, l12, t2 * ca));
+                        T[r][3] = fma(t0, l03, fma(t1, l13, fma(t2, dd, t3)));
+                    }
+                }
+            }
+            const double focal = lds_c[PC::kCam], center = lds_c[PC::kCam + 1];
             if constexpr (L == 1) {
 #pragma unroll
                 for (int pt = 0; pt < M / 2; ++pt) {
-                    const double *w = A.plant.points[pt];
-                    const double dx = w[0] - pos[0], dy = w[1] - pos[1], dz = w[2] - pos[2];
-                    const double xc = fma(rot[0], dx, fma(rot[3], dy, rot[6] * dz));
-                    const double yc = fma(rot[1], dx, fma(rot[4], dy, rot[7] * dz));
-                    const double iz = fast_rcp(fma(rot[2], dx, fma(rot[5], dy, rot[8] * dz)));
-                    z[2 * pt] = fma(A.plant.focal * xc, iz, A.plant.center);
-                    z[2 * pt + 1] = fma(A.plant.focal * yc, iz, A.plant.center);
+                    const double dx = lds_c[PC::kPoint + 3 * pt] - T[0][3], dy = lds_c[PC::kPoint + 3 * pt + 1] - T[1][3],
+                                 dz = lds_c[PC::kPoint + 3 * pt + 2] - T[2][3];
+                    const double xc = fma(T[0][0], dx, fma(T[1][0], dy, T[2][0] * dz));           // R^T (w - t)
+                    const double yc = fma(T[0][1], dx, fma(T[1][1], dy, T[2][1] * dz));
+                    const double iz = fast_rcp(fma(T[0][2], dx, fma(T[1][2], dy, T[2][2] * dz)));
+                    z[2 * pt] = fma(focal * xc, iz, center);
+                    z[2 * pt + 1] = fma(focal * yc, iz, center);
                 }
             } else {
-                // lane 0 owns the u rows, lane 1 the v rows of every point: pick the camera axis once
-                const double ax = sub ? rot[1] : rot[0], ay = sub ? rot[4] : rot[3], az = sub ? rot[7] : rot[6];
+                // even lanes own u rows, odd lanes v rows; each lane needs its camera axis (x or y), the optical axis and the position
+                const bool odd = sub & 1;
+                double va[3], vz[3], vp[3];
+                if constexpr (!SPLIT) {
 #pragma unroll
-                for (int pt = 0; pt < R; ++pt) {
-                    const double *w = A.plant.points[pt];
-                    const double dx = w[0] - pos[0], dy = w[1] - pos[1], dz = w[2] - pos[2];
-                    const double ic = fma(ax, dx, fma(ay, dy, az * dz));
-                    const double iz = fast_rcp(fma(rot[2], dx, fma(rot[5], dy, rot[8] * dz)));
-                    z[pt] = fma(A.plant.focal * ic, iz, A.plant.center);
+                    for (int r = 0; r < 3; ++r) { va[r] = odd ? T[r][1] : T[r][0]; vz[r] = T[r][2]; vp[r] = T[r][3]; }
+                } else {
+                    // right-to-left: start from the last group's columns, then apply the earlier groups' affine maps
+                    {
+                        double last[3][4];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) last[r][c] = pair_from<L, G - 1>(T[r][c]);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { va[r] = odd ? last[r][1] : last[r][0]; vz[r] = last[r][2]; vp[r] = last[r][3]; }
+                    }
+#pragma unroll
+                    for (int g = G - 2; g >= 0; --g) {
+                        double B[3][4];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) B[r][c] = pair_from_dyn<L>(T[r][c], g);
+                        double na[3], nz3[3], np[3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            na[r] = fma(B[r][0], va[0], fma(B[r][1], va[1], B[r][2] * va[2]));
+                            nz3[r] = fma(B[r][0], vz[0], fma(B[r][1], vz[1], B[r][2] * vz[2]));
+                            np[r] = fma(B[r][0], vp[0], fma(B[r][1], vp[1], fma(B[r][2], vp[2], B[r][3])));
+                        }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { va[r] = na[r]; vz[r] = nz3[r]; vp[r] = np[r]; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {                // row r*L + sub looks at point (r*L + sub) / 2
+                    double w[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if constexpr (L == 2) w[c] = lds_c[PC::kPoint + 3 * r + c];
+                        else w[c] = (sub & 2) ? lds_c[PC::kPoint + 3 * (2 * r + 1) + c] : lds_c[PC::kPoint + 3 * (2 * r) + c];
+                    }
+                    const double dx = w[0] - vp[0], dy = w[1] - vp[1], dz = w[2] - vp[2];
+                    const double ic = fma(va[0], dx, fma(va[1], dy, va[2] * dz));
+                    const double iz = fast_rcp(fma(vz[0], dx, fma(vz[1], dy, vz[2] * dz)));
+                    z[r] = fma(focal * ic, iz, center);
                 }
             }
         }
+        UVS_STAMP(0);                                            // noise-load issue + plant
         const double sigma = bandwidth(fp, k);
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
-        double *xb = s_x.row(k);
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
+        double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double fi = z[r] + nz[r];                      // noisy feature (experiment.py:134-135)
             const double zi = fi - f_prev[r];                    // measurement Z (experiment.py:170-177)
             f_prev[r] = fi;
-            double x[N], g[N];
+            double x[N], g[N], pb[NP];
 #pragma unroll
-            for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
+            for (int j = 0; j < N; ++j) x[j] = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
             double pred = 0.0;
 #pragma unroll
             for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
             const double nu = zi - pred;                         // innovation (experiment.py:274)
+#ifdef UVS_ABLATE_ROWS
 #pragma unroll
-            for (int l = 0; l < N; ++l) p[r][Sym<N>::at(l, l)] += 1.0;           // P + Q (experiment.py:167)
+            for (int l = 0; l < N; ++l) g[l] = pb[Sym<N>::at(l, l)] * dq[l];
+#else
+#pragma unroll
+            for (int l = 0; l < N; ++l) pb[Sym<N>::at(l, l)] += 1.0;             // P + Q (experiment.py:167)
 #pragma unroll
             for (int l = 0; l < N; ++l) {
-                double acc = p[r][Sym<N>::at(l, 0)] * dq[0];
+                double acc = pb[Sym<N>::at(l, 0)] * dq[0];
 #pragma unroll
-                for (int j = 1; j < N; ++j) acc = fma(p[r][Sym<N>::at(l, j)], dq[j], acc);
+                for (int j = 1; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], dq[j], acc);
                 g[l] = acc;
             }
+#endif
             double a = 0.0;
 #pragma unroll
             for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
             double gamma;
             if constexpr (METHOD == UVS_METHOD_GMCKF) {
+#ifdef UVS_ABLATE_EXP
+                kap[r] = fast_rcp(fma(nu * nu, -neg_half_inv_s2, 1.0));
+#else
                 kap[r] = exp((nu * nu) * neg_half_inv_s2);       // utils.py:171-172
+#endif
                 const double d = kap[r] + fp.reg;                // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
                 gamma = d * fast_rcp(fma(a, d, 1.0));
             } else {                                             // KF (experiment.py:192)
@@ -295,23 +463,42 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
             for (int j = 0; j < N; ++j) {
                 x[j] = fma(g[j], step, x[j]);                    // X + K (Z - H X) (experiment.py:291)
                 chk = fma(x[j], 0.0, chk);
-                lds_x[r * N + j][lane] = x[j];
+                if constexpr (XREG) xr[r][j] = x[j];
+                else lds_x[r * N + j][lane] = x[j];
             }
-            if (s_x.on && alive && valid) {
+            if constexpr (XOUT) {
+#ifdef UVS_ABLATE_STORES
+                if (k == K - 1)
+#endif
+                {
+                    double *pc = pxr;
 #pragma unroll
-                for (int j = 0; j < N; ++j) (xb + (r * L * N + j) * s_x.sc)[lo_x] = x[j];
+                    for (int j = 0; j < N; ++j) { *pc = x[j]; pc += A.x_out.sc; }
+                    pxr += L * N * A.x_out.sc;
+                }
             }
+#ifndef UVS_ABLATE_ROWS
 #pragma unroll
             for (int l = 0; l < N; ++l) {                        // Joseph update with R = 1: P -= beta g g^T
                 const double w = beta * g[l];
 #pragma unroll
-                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = fma(-w, g[j], p[r][Sym<N>::at(l, j)]);
+                for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
+            }
+#else
+            pb[0] = fma(-beta, g[0], pb[0]);
+#endif
+#pragma unroll
+            for (int e = 0; e < NP; ++e) {
+                if (r < PV) p[r < PV ? r : 0][e] = pb[e];
+                else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
             }
         }
-        // NB: the X rows of step k are stored before its FAIL test; a failing trial reports k_done = k and callers ignore rows
-        // >= k_done (the reference breaks before logging row k, experiment.py:313-316).
+        if constexpr (XOUT) px += A.x_out.sk;
+        // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
+        asm volatile("" ::: "memory");
+        UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
         chk = pair_sum<L>(chk);
-        if (alive && !(chk == 0.0)) {
+        if (alive && !(chk == 0.0)) {                            // pinv would raise (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
             k_done = k;
@@ -319,45 +506,83 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
         if (!__any(alive)) break;
 
         // ---- control law: dq = -gain * pinv(X) (kappa o err) (experiment.py:300-312)
+        double err[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) err[r] = f_prev[r] - des[r]; // experiment.py:302
+        double acc_now[3 * R];                                   // statistics accumulators: fetch early, their latency hides under the QR
+#pragma unroll
+        for (int i = 0; i < 3 * R; ++i) acc_now[i] = lds_acc[i][lane];
         {
             double panel[R][N + 1];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) panel[r][j] = lds_x[r * N + j][lane];
-                panel[r][N] = kap[r] * (f_prev[r] - des[r]);
+                for (int j = 0; j < N; ++j) panel[r][j] = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
+                panel[r][N] = kap[r] * err[r];
             }
             double sol[N];
+#ifdef UVS_ABLATE_QR
+#pragma unroll
+            for (int j = 0; j < N; ++j) sol[j] = pair_sum<L>(panel[j % R][j] * 1e-4 + panel[(j + 1) % R][N] * 1e-3);
+#else
             lstsq_tall_tuned<M, N, L>(panel, sub, sol);
+#endif
 #pragma unroll
             for (int j = 0; j < N; ++j) dq[j] = -fp.gain * sol[j];
         }
+        UVS_STAMP(2);                                            // control law
 
         // ---- logs and statistics
-        if (alive && valid) {
-            double *eb = s_err.row(k), *fb = s_f.row(k), *qb = s_q.row(k), *db = s_dq.row(k);
+        if (on_err) {
+            double *pc = pe;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double e = f_prev[r] - des[r];             // experiment.py:302
-                if (s_err.on) (eb + r * L * s_err.sc)[lo_err] = e;
-                if (s_f.on) (fb + r * L * s_f.sc)[lo_f] = f_prev[r];
-                const double ae = fabs(e);
-                lds_acc[r][lane] = fma(e, e, lds_acc[r][lane]);
-                lds_acc[R + r][lane] += ae;
-                lds_acc[2 * R + r][lane] = fma(t, ae, lds_acc[2 * R + r][lane]);
-            }
-            if (sub == 0) {
+            for (int r = 0; r < R; ++r) { *pc = err[r]; pc += L * A.err_out.sc; }
+            pe += A.err_out.sk;
+        }
+        if (on_f) {
+            double *pc = pf;
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    if (s_q.on) (qb + j * s_q.sc)[lo_q] = q[j];
-                    if (s_dq.on) (db + j * s_dq.sc)[lo_dq] = dq[j];
-                }
-            }
+            for (int r = 0; r < R; ++r) { *pc = f_prev[r]; pc += L * A.f_out.sc; }
+            pf += A.f_out.sk;
+        }
+        double dq_own[JG];                                       // the command for this lane's joints
+#pragma unroll
+        for (int u = 0; u < JG; ++u) {
+            if constexpr (G == 1) dq_own[u] = dq[u];
+            else if constexpr (G == 2) dq_own[u] = grp ? dq[JG + u] : dq[u];
+            else dq_own[u] = (grp == 0) ? dq[u] : (grp == 1 ? dq[JG + u] : dq[2 * JG + u]);
+        }
+        if (on_q) {
+            double *pc = pq;
+#pragma unroll
+            for (int u = 0; u < JG; ++u) { *pc = q[u]; pc += A.q_out.sc; }
+            pq += A.q_out.sk;
+        }
+        if (on_dq) {
+            double *pc = pd;
+#pragma unroll
+            for (int u = 0; u < JG; ++u) { *pc = dq_own[u]; pc += A.dq_out.sc; }
+            pd += A.dq_out.sk;
         }
 #pragma unroll
-        for (int j = 0; j < N; ++j) q[j] = fma(dq[j], fp.dt, q[j]);            // new_q = q + dq t_s (experiment.py:320)
+        for (int r = 0; r < R; ++r) {
+            const double e = alive ? err[r] : 0.0;               // a failed trial stops contributing (its stats are discarded anyway)
+            const double ae = fabs(e);
+            lds_acc[r][lane] = fma(e, e, acc_now[r]);
+            lds_acc[R + r][lane] = acc_now[R + r] + ae;
+            lds_acc[2 * R + r][lane] = fma(t, ae, acc_now[2 * R + r]);
+        }
+        UVS_STAMP(3);                                            // logs + statistics
+#pragma unroll
+        for (int u = 0; u < JG; ++u) q[u] = fma(dq_own[u], fp.dt, q[u]);       // new_q = q + dq t_s (experiment.py:320)
         t += fp.dt;
     }
+#ifdef UVS_STAMPS
+    if (lane == 0 && A.stats) {
+        for (int c = 0; c < 6; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
+    }
+    return;
+#endif
 
     double s2[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -371,7 +596,6 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
 #pragma unroll
     for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
     if (!valid) return;
-    const long long trial = wave_first + tl;
     if (sub == 0) {
         if (A.stats) {
 #pragma unroll
@@ -384,7 +608,8 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j < N; ++j) *A.x_final.at(trial, 0, (r * L + sub) * N + j) = lds_x[r * N + j][lane];
+            for (int j = 0; j < N; ++j)
+                *A.x_final.at(trial, 0, (r * L + sub) * N + j) = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
     }
     if (A.p_final.on()) {
 #pragma unroll
@@ -392,7 +617,9 @@ __global__ __launch_bounds__(64) void closed_loop_tuned_kernel(const ClosedArgs 
 #pragma unroll
             for (int l = 0; l < N; ++l)
 #pragma unroll
-                for (int j = 0; j < N; ++j) *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) = p[r][Sym<N>::at(l, j)];
+                for (int j = 0; j < N; ++j)
+                    *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) =
+                        (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }
 }
 

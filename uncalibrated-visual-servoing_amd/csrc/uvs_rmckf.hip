@@ -334,12 +334,12 @@ int check_launch(const char *what) {
 
 // (m, n, lanes-per-filter) instantiations; the first listed L of a shape is its default.
 #define UVS_SHAPES(X) \
-    X(8, 6, 1) X(8, 6, 2) X(8, 6, 4) X(8, 6, 8) \
+    X(8, 6, 2) X(8, 6, 1) X(8, 6, 4) X(8, 6, 8) \
     X(2, 6, 1) \
-    X(6, 6, 1) X(6, 6, 2) \
+    X(6, 6, 2) X(6, 6, 1) \
     X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)
 
-#define UVS_TUNED_SHAPES(X) X(8, 6, 1) X(8, 6, 2) X(6, 6, 1) X(6, 6, 2)
+#define UVS_TUNED_SHAPES(X) X(8, 6, 1) X(8, 6, 2) X(8, 6, 4) X(6, 6, 2)
 
 int default_lanes(int m, int n) {
 #define X(M, N, L) if (m == M && n == N) return L;
@@ -361,6 +361,21 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
 }
 
 dim3 grid_for(int64_t T, int L) { return dim3((unsigned)((T * L + 63) / 64)); }
+
+// Tuned closed-loop kernel: estimator, plant kind and "X stream wanted" are compile-time there.
+template <int M, int N, int LL, int METHOD, int PLANT>
+void launch_tuned2(bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
+    constexpr int PV = (LL == 2 ? M / LL / 2 : M / LL);      // L = 2 parks half of its blocks in LDS; 1 and 4 keep all in registers
+    if (xo) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, METHOD, PLANT, PV, true>), g, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, METHOD, PLANT, PV, false>), g, dim3(64), 0, s, A);
+}
+template <int M, int N, int LL>
+void launch_tuned(bool gmckf, bool linear, bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
+    if (gmckf && !linear) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
+    else if (gmckf) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>(xo, g, s, A);
+    else if (!linear) launch_tuned2<M, N, LL, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
+    else launch_tuned2<M, N, LL, UVS_METHOD_KF, UVS_PLANT_LINEAR>(xo, g, s, A);
+}
 
 }  // namespace
 
@@ -404,16 +419,12 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     A.stats = stats; A.status = status; A.k_done = k_done;
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
-    // lanes_per_filter 1 / 2 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic
+    // lanes_per_filter 1 / 2 / 4 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic
     // template with |value| lanes (kept as an in-library cross-check of the tuned code).
     const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF) && fp->lanes_per_filter >= 0;
 #define XT(M, N, LL) \
     if (!launched && tuned_ok && L == LL && fp->m == M && fp->n == N) { \
-        const bool gm = fp->method == UVS_METHOD_GMCKF, lin = plant->kind == UVS_PLANT_LINEAR; \
-        if (gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>), grid_for(T, LL), dim3(64), 0, s, A); \
-        if (gm && lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>), grid_for(T, LL), dim3(64), 0, s, A); \
-        if (!gm && !lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>), grid_for(T, LL), dim3(64), 0, s, A); \
-        if (!gm && lin) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, UVS_METHOD_KF, UVS_PLANT_LINEAR>), grid_for(T, LL), dim3(64), 0, s, A); \
+        launch_tuned<M, N, LL>(fp->method == UVS_METHOD_GMCKF, plant->kind == UVS_PLANT_LINEAR, x_out.base != nullptr, grid_for(T, LL), s, A); \
         launched = true; \
     }
     UVS_TUNED_SHAPES(XT)
