@@ -219,6 +219,29 @@ def test_stats_kernel_matches_matlab_definition(uvs):
         assert rel_err(got[j], trial_stats(err[j, :k_done[j]], t[:k_done[j]])) <= 1e-12
 
 
+# ---------------------------------------------------------------------------------------------- bulk check against the C oracle
+def test_monte_carlo_batch_matches_c_oracle(uvs):
+    """2 048 trials of BASELINE config 2 (alpha-stable alpha = 1.5, jittered starts, product noise generator) through the
+    default kernel and through oracle/c: trajectories, statistics, status."""
+    from oracle import c_oracle
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = 2048
+    plan = uvs.batch.plan_trials(cfg, cells=[1.5])
+    K = 299
+    noise = np.zeros((len(plan), K, 8))
+    uvs.batch.trial_noise(cfg, plan, 0, len(plan), K, noise)
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True)
+    out = uvs.engine.closed_loop(fp, uvs.SyntheticPlant.ur10().to_struct(), _cuda(plan.q_start), _cuda(noise.transpose(1, 2, 0)), want=('err', 'q'))
+    ref = c_oracle.closed_loop_batch(plan.q_start, noise, cfg['experiments']['desired_f'])
+    assert np.array_equal(out['status'].cpu().numpy(), ref['status']) and np.array_equal(out['k_done'].cpu().numpy(), ref['k_done'])
+    err = out['err'].cpu().numpy().transpose(2, 0, 1)
+    dev = np.abs(err - ref['err']).max(axis=(1, 2)) / np.abs(ref['err']).max(axis=(1, 2))
+    assert np.median(dev) <= 1e-11 and np.quantile(dev, 0.99) <= 1e-8 and dev.max() <= 1e-5          # contract: 1e-5 relative
+    sdev = np.abs(out['stats'].cpu().numpy() - ref['stats']) / ref['stats']
+    assert sdev.max() <= 1e-7
+
+
 # ---------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_batch_properties(uvs):
     """BASELINE config 2 size (65 536 trials x 299 steps): results do not depend on batch position or launch

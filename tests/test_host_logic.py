@@ -1,0 +1,185 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/uvs_rmckf.h (no compute calls), and the host
+logic around it (config validation, trial enumeration, loop clock, batched noise, statistics, API surface)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden
+
+
+@pytest.fixture(scope='module')
+def uvs():
+    import uvs_amd
+    return uvs_amd
+
+
+def test_library_exports_every_header_symbol(uvs):
+    header = open(os.path.join(ROOT, 'include', 'uvs_rmckf.h')).read()
+    declared = set(re.findall(r'\b(uvs_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(uvs._lib.SYMBOLS), 'ctypes table and header disagree'
+    handle = uvs.lib()
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert handle.uvs_version().startswith(b'uvs_rmckf')
+
+
+def test_struct_layouts_match_the_header(uvs):
+    # sizes implied by include/uvs_rmckf.h (LP64): catches a drifted ctypes mirror before it corrupts a launch
+    assert ctypes.sizeof(uvs._lib.View) == 32
+    assert ctypes.sizeof(uvs._lib.FilterParams) == 8 * 4 + 5 * 8 + 32 * 8
+    assert ctypes.sizeof(uvs._lib.Plant) == 8 + 5 * 8 * 8 + 16 * 3 * 8 + 16 + 8 + 24
+
+
+def test_argument_errors_are_reported_not_thrown(uvs):
+    lib = uvs.lib()
+    V = uvs._lib.NULL_VIEW
+    rc = lib.uvs_rmckf_replay_f64(None, 4, V, V, V, V, V, V, V, None, None, V, V, None)
+    assert rc == -1 and b'NULL' in lib.uvs_last_error()
+    fp = uvs.engine.make_params(5, 3, 'GMCKF', desired=np.zeros(5), steps=3)          # shape that is not instantiated
+    rc = lib.uvs_rmckf_replay_f64(ctypes.byref(fp), 4, V, V, V, V, V, V, V, None, None, V, V, None)
+    assert rc == -2
+    fp = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), steps=3)
+    rc = lib.uvs_rmckf_replay_f64(ctypes.byref(fp), 4, V, V, V, V, V, V, V, None, None, V, V, None)
+    assert rc == -4
+    assert lib.uvs_supported_lanes(8, 6, None, 0) >= 4 and lib.uvs_supported_lanes(7, 7, None, 0) == 0
+
+
+def test_missing_library_is_loud(uvs, monkeypatch):
+    monkeypatch.setattr(uvs._lib, '_lib', None)
+    monkeypatch.setattr(uvs._lib, 'LIB_PATH', '/nonexistent/libuvs_rmckf.so')
+    with pytest.raises(uvs.UvsLibraryError):
+        uvs._lib.lib()
+
+
+def test_no_gpu_means_no_result(uvs):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(uvs.UvsLibraryError):
+        uvs.Experiment([0.0] * 6, [0.0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.GMCKF, initial_guess=True,
+                       kernel_bw=10, fpi_threshold=0.1, fpi_epoch_max=10, annealing=False).run()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'uncalibrated-visual-servoing_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), f
+                assert 'oracle/' not in text or f == '_lib.py' or 'test infrastructure' in text, f
+
+
+# ---------------------------------------------------------------------------------------------- reference-format config
+def _ref_config():
+    return json.load(open(os.path.join(ROOT, 'tests', 'golden', 'config_reference.json')))
+
+
+def test_config_schema_and_validation(uvs):
+    cfg = _ref_config()
+    assert uvs.batch.load_config(cfg)['estimator']['method'] == 'MCKF'                 # the reference's shipped default
+    bad = json.loads(json.dumps(cfg)); del bad['noise']['hold_time']
+    with pytest.raises(KeyError):
+        uvs.batch.load_config(bad)
+    bad = json.loads(json.dumps(cfg)); bad['estimator']['method'] = 'RMCKF'             # the paper's name is not an enum member
+    with pytest.raises(ValueError):
+        uvs.batch.load_config(bad)
+    bad = json.loads(json.dumps(cfg)); bad['noise']['type'] = 'PINK'
+    with pytest.raises(ValueError):
+        uvs.batch.load_config(bad)
+
+
+def test_trial_plan_follows_main_py(uvs):
+    cfg = _ref_config()
+    plan = uvs.batch.plan_trials(cfg)
+    assert len(plan) == 12 * 100 and np.allclose(plan.cells, np.linspace(1, 2, 12))     # ALPHA_STABLE sweeps alpha (main.py:105-106)
+    assert list(plan.seed[:3]) == [123456, 123457, 123458] and plan.seed[-1] == 123456 + 1199   # global numbering, never reset
+    assert plan.cell[99] == 0 and plan.cell[100] == 1 and plan.value[1199] == 2.0
+    # jitter: survey Appendix B known answers for the first trial (main.py:132-134, "2 (r - 1)" formula)
+    assert plan.q_start[0, 0] == pytest.approx(-0.26971060839006766, abs=1e-15) and plan.q_start[0, 1] == pytest.approx(-0.229612873789818, abs=1e-15)
+    assert np.all(plan.q_start[:, 0] <= 0) and np.all(plan.q_start[:, 0] >= -np.pi / 9 - 1e-12)
+    jit = load_golden('noise_uniform_jitter')['values']
+    assert np.array_equal(plan.q_start[:300, 0], 2 * (jit[:, 0] - 1) * (np.pi / 18))
+    cfg['noise']['type'] = 'GAUSSIAN_MIXTURE'
+    cfg['noise']['noise_params'] = dict(std=1.0, mean=50.0, rho=0.0)
+    assert np.allclose(uvs.batch.plan_trials(cfg).cells, np.linspace(0, 0.2, 12))
+    cfg['experiments']['change_q_start'] = False
+    assert np.array_equal(uvs.batch.plan_trials(cfg).q_start[7], cfg['experiments']['q_start'])
+
+
+def test_loop_clock_matches_reference_logs(uvs):
+    t = uvs.engine.loop_clock(0.05, 15)
+    assert len(t) == 299 and np.array_equal(t, load_golden('closed_gmckf_a1p5')['t'])
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', desired=np.arange(8.0))
+    assert fp.steps == 299 and fp.k_max == 300 and fp.reg == 1e-6 and fp.anneal_span == 100 and list(fp.desired)[:8] == list(np.arange(8.0))
+
+
+@pytest.mark.parametrize('name', golden_names('noise_'))
+def test_noise_profiler_and_batch_reproduce_reference_streams(uvs, name):
+    g = load_golden(name)
+    meta = g['meta']
+    nt = uvs.NoiseType[meta['noise_type']]
+    prof = uvs.NoiseProfiler(meta['m'], nt, seed=meta['seed'], noise_hold=meta['hold'], noise_hold_cnt=meta['hold_cnt'], noise_params=meta['noise_params'])
+    buf = prof.getNoise()
+    first = buf.copy()
+    assert prof.getNoise() is buf                                                        # aliased buffer, like noise.py:118
+    rest = np.stack([prof.getNoise().copy() for _ in range(len(g['values']) - 2)])
+    assert np.array_equal(first, g['values'][0]) and np.array_equal(rest, g['values'][2:])
+    got = uvs.noise_batch(nt, meta['noise_params'], [meta['seed'], meta['seed'] + 1], meta['m'], len(g['values']), meta['hold'], meta['hold_cnt'])
+    # uniform / normal / Cauchy / mixtures are bit-identical; the CMS transform may differ in the last bits (array vs scalar libm)
+    assert np.allclose(got[0], g['values'], rtol=1e-14, atol=0)
+    assert not np.array_equal(got[0], got[1])
+
+
+def test_trial_noise_assigns_cells_and_seeds(uvs):
+    cfg = _ref_config()
+    cfg['experiments']['epoch'] = 3
+    plan = uvs.batch.plan_trials(cfg)
+    K = 20
+    out = np.zeros((len(plan), K, 8))
+    uvs.batch.trial_noise(cfg, plan, 0, len(plan), K, out)
+    for t in (0, 4, 35):
+        p = dict(cfg['noise']['noise_params'], alpha=float(plan.value[t]))
+        prof = uvs.NoiseProfiler(8, uvs.NoiseType.ALPHA_STABLE, seed=int(plan.seed[t]), noise_params=p)
+        ref = np.stack([prof.getNoise().copy() for _ in range(K)])
+        assert np.allclose(out[t], ref, rtol=1e-14, atol=0)
+
+
+def test_cell_summary_matches_matlab_definitions(uvs):
+    rng = np.random.default_rng(0)
+    stats, status, cell = rng.uniform(1, 2, (40, 3)), np.zeros(40, int), np.repeat([0, 1], 20)
+    status[[3, 25]] = 1
+    s = uvs.stats.cell_summary(stats, status, cell)
+    ok0 = np.delete(np.arange(20), 3)
+    assert s[0]['success'] == 19 and s[0]['itae_mean'] == pytest.approx(stats[ok0, 2].mean())
+    assert s[0]['itae_std'] == pytest.approx(stats[ok0, 2].std(ddof=1)) and s[1]['iae_median'] == pytest.approx(np.median(np.delete(stats[20:, 1], 5)))
+
+
+def test_api_surface_keeps_reference_names(uvs):
+    assert [m.name for m in uvs.Method] == ['ANALYTICAL', 'KF', 'MCKF', 'IMCCKF', 'GMCKF'] and uvs.Method.GMCKF.value == 5
+    assert [s.name for s in uvs.ExperimentStatus] == ['SUCCESS', 'FAIL'] and str(uvs.ExperimentStatus.SUCCESS) == 'ExperimentStatus.SUCCESS'
+    assert [n.name for n in uvs.NoiseType] == ['WHITE_NOISE', 'GAUSSIAN_MIXTURE', 'GAUSSIAN_BIMODAL', 'ALPHA_STABLE', 'UNIFORM']
+    assert uvs.NoiseType.numberOfGenerators(uvs.NoiseType.GAUSSIAN_BIMODAL) == 3
+    assert uvs.gaussianKernel(3.0, 2.0) == np.exp(-0.5 * 9 / 4)
+    ex = uvs.Experiment(q_start=[0] * 6, desired_f=[0] * 8, noise_prof=None, t_s=0.05, t_max=15, ibvs_gain=0.2, robot=object(),
+                        method=uvs.Method.GMCKF, method_params=dict(initial_guess=True, kernel_bw=10, fpi_threshold=0.1, fpi_epoch_max=9, annealing=True))
+    assert ex.kernel_bw == 10 and ex.annealing is True and ex.fpi_epoch_max == 9       # nested-dict convention (experiment.py:29-30)
+    assert len(uvs.batch.CSV_COLUMNS) == 41 and uvs.batch.CSV_COLUMNS[:4] == ['experiment_id', 'status', 'rho', 't']
+
+
+def test_synthetic_plant_matches_oracle_plant(uvs):
+    from oracle import plant_ref
+    plant = uvs.SyntheticPlant.ur10()
+    assert np.array_equal(plant.points, plant_ref.place_discs())
+    q = np.array([0.1, -0.4, 1.9, 0.2, -1.5, 0.3])
+    Ts, Tr = plant.fkine_all(q), plant_ref.fkine_all(q)
+    assert all(np.array_equal(a, b) for a, b in zip(Ts, Tr)) and np.array_equal(plant.jacobian(Ts), plant_ref.geometric_jacobian(Tr))
+    s = plant.to_struct()
+    assert s.n_joints == 6 and s.n_points == 4 and s.kind == 0 and s.cos_alpha[0] == np.cos(-np.pi / 2)
+    robot = uvs.SyntheticRobot(dt=0.05)
+    robot.start(q)
+    assert robot.sim.getSimulationTime() == 0.05 and np.array_equal(robot.features(), plant_ref.project(Tr[5], plant.points))

@@ -3,7 +3,7 @@
 Keeps the reference's ``config.json`` schema (main.py:16-98), sweep cells (``linspace(0, .2, 12)`` of rho, or
 ``linspace(1, 2, 12)`` of alpha for ALPHA_STABLE, main.py:104-106), global trial numbering, per-trial noise seed
 ``seed + trial`` (main.py:137-139), the q_start jitter stream ``NoiseProfiler(2, UNIFORM, seed=experiment_seed)`` with
-the ``2 (r - 1)`` formula (main.py:118, 132-134) and the 43-column results.csv (main.py:152-196).
+the ``2 (r - 1)`` formula (main.py:118, 132-134) and the 41-column results.csv (main.py:152-196; SURVEY.md says 43, the DataFrame has 4 + 6 + 6 + 8 + 8 + 8 + 1 = 41).
 """
 import json
 import os
@@ -145,7 +145,7 @@ CSV_COLUMNS = (['experiment_id', 'status', 'rho', 't'] + [f'q_{i}' for i in rang
 
 
 def write_results_csv(result, cfg, plant, path):
-    """results.csv in the reference's long format (main.py:152-196): one row per logged step, 43 columns.  Needs the
+    """results.csv in the reference's long format (main.py:152-196): one row per logged step, 41 columns.  Needs the
     'q' and 'f' streams; meant for sweeps of the reference's size (~10^3 trials) -- larger runs keep tensors/npz."""
     import pandas as pd
     q = result.streams['q'].cpu().numpy()

@@ -78,7 +78,7 @@ class Experiment:
 
     # ---- route 1: plant inside the kernel ------------------------------------------------------------
     def _run_on_device_plant(self):
-        import torch
+        torch = engine._torch()                                  # raises UvsLibraryError without a GPU: there is no CPU fallback
         robot, m = self.robot, len(self.desired_f)
         n = robot.plant.n_joints
         t_log = engine.loop_clock(self.t_s, self.t_max)
@@ -114,7 +114,7 @@ class Experiment:
 
     # ---- route 2: external robot, estimator step on the GPU ------------------------------------------
     def _run_with_external_robot(self):
-        import torch
+        torch = engine._torch()
         robot = self.robot
         robot.start(self.q_start)
         m, n = len(self.desired_f), 6
