@@ -29,6 +29,10 @@ namespace uvs {
         stamp_sum[slot] += now_ - stamp_last;                                             \
         stamp_last = now_;                                                                \
     } while (0)
+#elif defined(UVS_PHASE_FENCE)
+// Keep the scheduler from interleaving instructions across phase boundaries: with a register file this full, cross-phase
+// hoisting lengthens live ranges into spills (measured on L = 4: 4.6 ms -> 3.6 ms).
+#define UVS_STAMP(slot) __builtin_amdgcn_sched_barrier(0)
 #else
 #define UVS_STAMP(slot) do { } while (0)
 #endif
@@ -72,12 +76,19 @@ UVS_DEV double pair_from_dyn(double v, int owner) {      // owner is a compile-t
         default: return pair_from<L, (L > 2 ? 3 : 0)>(v);
     }
 }
+// Pin a value in a VGPR.  Without it LLVM folds "cond ? a[1] : a[0]" on a register-resident array into a variably indexed
+// access, which on AMDGPU means: spill the array to scratch and load it back through memory -- per lane, per step.
+UVS_DEV double in_reg(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 // Per-lane choice among the L values v[0..L) by the lane's position in its group.
 template <int L>
 UVS_DEV double pick_sub(const double *v, int sub) {
     if constexpr (L == 1) return v[0];
-    if constexpr (L == 2) return sub ? v[1] : v[0];
-    return (sub & 2) ? ((sub & 1) ? v[3] : v[2]) : ((sub & 1) ? v[1] : v[0]);
+    if constexpr (L == 2) return sub ? in_reg(v[1]) : in_reg(v[0]);
+    const double lo = (sub & 1) ? in_reg(v[1]) : in_reg(v[0]), hi = (sub & 1) ? in_reg(v[3]) : in_reg(v[2]);
+    return (sub & 2) ? hi : lo;
 }
 
 // Householder QR least squares, rows interleaved over the L lanes of a filter: local row r of lane s is global row r*L + s.
@@ -154,7 +165,11 @@ struct PlantLds {
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
 __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
+#ifdef UVS_L4_XLDS
+    constexpr bool XREG = false;
+#else
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
+#endif
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool SPLIT = (PLANT == UVS_PLANT_DH_PINHOLE) && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             double cand[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) cand[g] = q_all[g * JG + u];
-            q[u] = (G == 1) ? cand[0] : (G == 2 ? (grp ? cand[1] : cand[0]) : (grp == 0 ? cand[0] : (grp == 1 ? cand[1] : cand[G - 1])));
+            q[u] = (G == 1) ? cand[0] : (G == 2 ? (grp ? in_reg(cand[1]) : in_reg(cand[0])) : (grp == 0 ? in_reg(cand[0]) : (grp == 1 ? in_reg(cand[1]) : in_reg(cand[G - 1]))));
         }
         double x0[R][N];
         if (fp.initial_guess) {
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                 double va[3], vz[3], vp[3];
                 if constexpr (!SPLIT) {
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) { va[r] = odd ? T[r][1] : T[r][0]; vz[r] = T[r][2]; vp[r] = T[r][3]; }
+                    for (int r = 0; r < 3; ++r) { va[r] = odd ? in_reg(T[r][1]) : in_reg(T[r][0]); vz[r] = T[r][2]; vp[r] = T[r][3]; }
                 } else {
                     // right-to-left: start from the last group's columns, then apply the earlier groups' affine maps
                     {
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
                             for (int c = 0; c < 4; ++c) last[r][c] = pair_from<L, G - 1>(T[r][c]);
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) { va[r] = odd ? last[r][1] : last[r][0]; vz[r] = last[r][2]; vp[r] = last[r][3]; }
+                        for (int r = 0; r < 3; ++r) { va[r] = odd ? in_reg(last[r][1]) : in_reg(last[r][0]); vz[r] = last[r][2]; vp[r] = last[r][3]; }
                     }
 #pragma unroll
                     for (int g = G - 2; g >= 0; --g) {
@@ -549,8 +564,8 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
         for (int u = 0; u < JG; ++u) {
             if constexpr (G == 1) dq_own[u] = dq[u];
-            else if constexpr (G == 2) dq_own[u] = grp ? dq[JG + u] : dq[u];
-            else dq_own[u] = (grp == 0) ? dq[u] : (grp == 1 ? dq[JG + u] : dq[2 * JG + u]);
+            else if constexpr (G == 2) dq_own[u] = grp ? in_reg(dq[JG + u]) : in_reg(dq[u]);
+            else dq_own[u] = (grp == 0) ? in_reg(dq[u]) : (grp == 1 ? in_reg(dq[JG + u]) : in_reg(dq[2 * JG + u]));
         }
         if (on_q) {
             double *pc = pq;
