@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--trials', type=int, default=TRIALS_PER_GPU, help='trials per GPU (default = BASELINE config 2)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layout', default='kct', choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -153,6 +154,8 @@ def main():
 
     t0 = time.perf_counter()
     noise = torch.as_tensor(noise_host, device=dev)               # PCIe upload, outside the timed region
+    if args.layout != 'kct':                                      # noise_host is [step][comp][trial]
+        noise = noise.permute({'ktc': (0, 2, 1), 'tkc': (2, 0, 1)}[args.layout]).contiguous()
     q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
     torch.cuda.synchronize()
     h2d_s = time.perf_counter() - t0
@@ -163,7 +166,7 @@ def main():
     plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
     T = hi - lo
     # output buffers are allocated once and reused by every step (engine.closed_loop allocates; here we pre-allocate by hand)
-    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev, zero=True) for k, c in (('x', 48), ('err', 8), ('q', 6))}
+    bufs = {k: engine.alloc_stream(T, K, c, args.layout, dev, zero=True) for k, c in (('x', 48), ('err', 8), ('q', 6))}
     stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
     status = torch.zeros(T, dtype=torch.int32, device=dev)
     k_done = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -173,8 +176,8 @@ def main():
 
     def launch():
         rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise), NV, engine.stream_view(bufs['x']),
-            engine.stream_view(bufs['err']), engine.stream_view(bufs['q']), NV, NV, stats.data_ptr(), status.data_ptr(),
+            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV, engine.stream_view(bufs['x'], args.layout),
+            engine.stream_view(bufs['err'], args.layout), engine.stream_view(bufs['q'], args.layout), NV, NV, stats.data_ptr(), status.data_ptr(),
             k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         uvs_amd._lib.check(rc)
 
@@ -233,7 +236,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, '
                                    f'{T} trials/GPU x {K} updates, X+err+q logged per step', 'trials_per_gpu': T, 'updates_per_trial': K,
-                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0], 'failed_trials': int((status != 0).sum().item())},
+                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0], 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'closed_loop_kernel<8,6,L>', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},

@@ -37,6 +37,23 @@ UVS_DEV void fast_sqrt_rsqrt(double a, double &s, double &rs) {
     rs = h + h;
 }
 
+// 1/d to ~1e-14 relative (one Newton step): for scale factors whose error only perturbs an orthogonal transform.
+UVS_DEV double fast_rcp_1(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    return fma(r, fma(-d, r, 1.0), r);
+}
+
+// sqrt(a) to ~1 ulp and 1/sqrt(a) to ~1e-14 relative: one coupled Newton step from v_rsq_f64 plus the final sqrt correction.
+UVS_DEV void fast_sqrt_rsqrt_1(double a, double &s, double &rs) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    s = fma(fma(-g, g, a), h, g);
+    rs = h + h;
+}
+
 // sin and cos for |x| <= ~1e5 rad: Cody-Waite reduction by pi/2 in three 33-bit pieces (exact products for
 // |k| < 2^20), then the classic minimax kernels on [-pi/4, pi/4] (fdlibm-style coefficients).  < 1 ulp.
 UVS_DEV void sincos_bounded(double x, double &s, double &c) {

@@ -112,11 +112,13 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         const double piv = pair_from_dyn<L>(a[m][c], owner);
         const double n2 = fma(piv, piv, sig);
         double nrm, rn;
-        fast_sqrt_rsqrt(n2, nrm, rn);
+        fast_sqrt_rsqrt_1(n2, nrm, rn);                                 // |R_cc| and its reciprocal
         const bool zero = !(n2 > 0.0);
-        const double alpha = (piv >= 0.0) ? -nrm : nrm;
-        const double vp = piv - alpha;
-        const double tau = zero ? 0.0 : fast_rcp(-alpha * vp);          // 2 / (v.v)
+        const bool neg = !(piv >= 0.0);
+        const double alpha = neg ? nrm : -nrm;                          // R_cc = -sign(piv) |column|
+        const double vp = piv - alpha;                                  // = sign(piv) (|piv| + nrm)
+        // tau = 2 / (v.v) = 1 / (nrm (nrm + |piv|)) = rn / |vp|
+        const double tau = zero ? 0.0 : rn * fast_rcp_1(fabs(vp));
         const double vm = is_piv ? vp : (is_below ? a[m][c] : 0.0);     // this lane's entry of the Householder vector in row m
 #pragma unroll
         for (int j = c + 1; j <= N; ++j) {
@@ -128,7 +130,7 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
 #pragma unroll
             for (int r = m + 1; r < R; ++r) a[r][j] = fma(-d, a[r][c], a[r][j]);
         }
-        rdiag[c] = zero ? 0.0 : fast_rcp(alpha);
+        rdiag[c] = zero ? 0.0 : (neg ? rn : -rn);                       // 1 / R_cc straight from the rsqrt
     }
 #pragma unroll
     for (int c = N - 1; c >= 0; --c) {
