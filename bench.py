@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--trials', type=int, default=TRIALS_PER_GPU, help='trials per GPU (default = BASELINE config 2)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
     ap.add_argument('--layout', default='kct', choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams')
     args = ap.parse_args()
 
@@ -140,9 +141,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(plan.q_start)
-    t0 = time.perf_counter()
-    noise_host = host_noise(plan.seed[lo:hi], K, workers)
-    gen_s = time.perf_counter() - t0
+    noise_host, gen_s = None, 0.0
+    if args.host_noise:
+        t0 = time.perf_counter()
+        noise_host = host_noise(plan.seed[lo:hi], K, workers)
+        gen_s = time.perf_counter() - t0
 
     import torch
     torch.cuda.set_device(local_rank)
@@ -153,7 +156,12 @@ def main():
     uvs_amd.lib()
 
     t0 = time.perf_counter()
-    noise = torch.as_tensor(noise_host, device=dev)               # PCIe upload, outside the timed region
+    if args.host_noise:
+        noise = torch.as_tensor(noise_host, device=dev)           # PCIe upload, outside the timed region
+    else:                                                         # NoiseProfiler-compatible streams generated on the GPU
+        noise = batch.device_noise(cfg, plan, lo, hi, K, dev)
+        torch.cuda.synchronize()
+        gen_s = time.perf_counter() - t0
     if args.layout != 'kct':                                      # noise_host is [step][comp][trial]
         noise = noise.permute({'ktc': (0, 2, 1), 'tkc': (2, 0, 1)}[args.layout]).contiguous()
     q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
@@ -241,8 +249,9 @@ def main():
                          'traffic': traffic, 'kernel': 'closed_loop_kernel<8,6,L>', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
             'cpu_baseline': cpu,
-            'setup': {'noise_gen_s': gen_s, 'noise_gen_workers': workers, 'h2d_s': h2d_s,
-                      'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if world == 1 else None},
+            'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
+                      'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
+                      'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},
         }
         print(json.dumps(line))
     if world > 1:

@@ -148,6 +148,31 @@ int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double
 int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const double *t, const int32_t *k_done,
                          double *stats, void *stream);
 
+/* noise.py:7-12 (NoiseType) */
+enum { UVS_NOISE_WHITE = 1, UVS_NOISE_GAUSSIAN_MIXTURE = 2, UVS_NOISE_GAUSSIAN_BIMODAL = 3, UVS_NOISE_ALPHA_STABLE = 4, UVS_NOISE_UNIFORM = 5 };
+
+/* Parameters of NoiseProfiler (noise.py:31-79).  The derived fields are filled by the host with the same Python float
+ * arithmetic the reference uses, so that no rounding differs: inv_alpha = 1/alpha, expo = (1-alpha)/alpha,
+ * cms_const = beta*tan(pi*alpha/2), cms_B = arctan(cms_const), cms_S = (1+cms_const^2)^(1/(2 alpha)) (noise.py:191-196),
+ * shift = (2/pi)*beta*gamma*log(gamma) (noise.py:203), sqrt2 = sqrt(2) (noise.py:181), two_over_pi = 2/pi (noise.py:199). */
+typedef struct uvs_noise_params {
+    int32_t type, m, steps, hold_cnt;       /* hold_cnt = noise_hold ? noise_hold_cnt : 0 */
+    double std, mean, rho;
+    double alpha, beta, gamma, delta;
+    double inv_alpha, expo, one_minus_alpha, cms_const, cms_B, cms_S, shift, sqrt2, two_over_pi;
+} uvs_noise_params;
+
+/*
+ * Noise streams of T trials generated on the device: out[t][k][i] is the k-th getNoise() value of feature i of
+ * NoiseProfiler(m, type, seed_t, ...) (noise.py:81-118), where the trial's generators were seeded on the host:
+ *   states [T][n_gen][4] uint64 (device) = (state_hi, state_lo, inc_hi, inc_lo) of PCG64(seed_t + 10*j) for j < gens*m
+ *          (noise.py:66-70) followed, for the mixtures, by PCG64(2*seed_t + i) for i < m (noise.py:55-59);
+ *   zig    768 doubles (device): numpy's ziggurat tables fi[256], wi[256], ki[256] (ki as raw uint64 bits).
+ * Uniform, normal and mixture streams reproduce numpy bit for bit (tail samples of the normal to 1-2 ulp); Cauchy and the
+ * Chambers-Mallows-Stuck transforms agree to a few ulp (device libm vs host libm).
+ */
+int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream);
+
 /*
  * Test hook: evaluates the library's fp64 helper functions on the device so that tests can bound their error against
  * numpy.  which: 0 fast reciprocal, 1 sqrt, 2 rsqrt, 3 sin, 4 cos (bounded-argument sincos with library fallback), 5 exp.

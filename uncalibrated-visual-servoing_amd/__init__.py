@@ -4,7 +4,7 @@ Modules keep the reference's names: ``experiment`` (Experiment, Method, Experime
 NoiseType), ``utils`` (gaussianKernel).  ``batch`` is the Monte-Carlo driver (main.py of the reference), ``engine`` the
 thin typed layer over the C ABI in ``include/uvs_rmckf.h``, ``plant`` the synthetic robot.
 """
-from . import _lib, utils, noise, plant, engine, experiment, stats, batch, dist  # noqa: F401
+from . import _lib, utils, noise, pcg, plant, engine, noise_device, experiment, stats, batch, dist  # noqa: F401
 from ._lib import UvsError, UvsLibraryError, build, lib  # noqa: F401
 from .experiment import Experiment, ExperimentStatus, Method  # noqa: F401
 from .noise import NoiseProfiler, NoiseType, noise_batch  # noqa: F401

@@ -37,6 +37,12 @@ class FilterParams(C.Structure):
                 ('reg', C.c_double), ('desired', C.c_double * UVS_MAX_M)]
 
 
+class NoiseParams(C.Structure):
+    _fields_ = [('type', C.c_int32), ('m', C.c_int32), ('steps', C.c_int32), ('hold_cnt', C.c_int32)] + \
+               [(k, C.c_double) for k in ('std', 'mean', 'rho', 'alpha', 'beta', 'gamma', 'delta', 'inv_alpha', 'expo', 'one_minus_alpha',
+                                          'cms_const', 'cms_B', 'cms_S', 'shift', 'sqrt2', 'two_over_pi')]
+
+
 class Plant(C.Structure):
     _fields_ = [('n_joints', C.c_int32), ('n_points', C.c_int32),
                 ('theta_offset', C.c_double * UVS_MAX_N), ('d', C.c_double * UVS_MAX_N), ('a', C.c_double * UVS_MAX_N),
@@ -57,6 +63,7 @@ SYMBOLS = {
     'uvs_rmckf_step_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [_VP] * 5 + [_I32, _I32] + [_VP] * 4 + [_VP]),
     'uvs_stats_reduce_f64': (C.c_int, [_I64, _I32, _I32, View, _VP, _VP, _VP, _VP]),
     'uvs_debug_math_f64': (C.c_int, [_I32, _I64, _VP, _VP, _VP]),
+    'uvs_noise_generate_f64': (C.c_int, [C.POINTER(NoiseParams), _I64, _VP, _VP, View, _VP]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import dist, engine
+from . import dist, engine, noise_device
 from .experiment import ExperimentStatus, Method
 from .noise import NoiseProfiler, NoiseType, noise_batch
 from .plant import SyntheticPlant
@@ -102,9 +102,27 @@ class BatchResult:
     seconds: float = 0.0
 
 
+def device_noise(cfg, plan, lo, hi, steps, device='cuda'):
+    """Noise streams of trials lo..hi generated on the GPU (noise_device.py), [step][feature][trial]."""
+    nz = cfg['noise']
+    noise_type = NoiseType[nz['type']]
+    m = len(cfg['experiments']['desired_f'])
+    hold_cnt = int(nz['hold_time'] / cfg['experiments']['dt'])      # main.py:137
+    key = 'alpha' if noise_type == NoiseType.ALPHA_STABLE else 'rho'
+    out = engine.alloc_stream(hi - lo, steps, m, 'kct', device)
+    for c in np.unique(plan.cell[lo:hi]):
+        idx = np.nonzero(plan.cell[lo:hi] == c)[0]                  # cells are contiguous runs of trials (main.py:121-127)
+        params = dict(nz['noise_params'])
+        params[key] = float(plan.cells[c])                          # main.py:123-126
+        a, b = int(idx[0]), int(idx[-1]) + 1
+        noise_device.generate(noise_type, params, plan.seed[lo:hi][a:b], m, steps, nz['hold'], hold_cnt, 'kct', out=out[:, :, a:b], device=device)
+    return out
+
+
 def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('err',), lanes=0, noise_tensor=None,
-              device='cuda'):
-    """Run this rank's shard of the sweep on its GPU.  Returns a BatchResult whose tensors stay on the device."""
+              device='cuda', noise_on_device=True):
+    """Run this rank's shard of the sweep on its GPU.  Returns a BatchResult whose tensors stay on the device.
+    ``noise_on_device``: generate the measurement noise with the HIP generator (default) or with numpy on the host."""
     import torch
     cfg = load_config(cfg)
     ex, est = cfg['experiments'], cfg['estimator']
@@ -121,6 +139,8 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
     t_log = engine.loop_clock(ex['dt'], ex['t_max'])
     K, Tl = len(t_log), hi - lo
     dev = torch.device(device)
+    if noise_tensor is None and noise_on_device:
+        noise_tensor = device_noise(cfg, plan, lo, hi, K, dev)
     if noise_tensor is None:
         host = np.empty((K, m, Tl))
         trial_noise(cfg, plan, lo, hi, K, host.transpose(2, 0, 1))  # logical [trial][step][m] view of the trial-fastest buffer

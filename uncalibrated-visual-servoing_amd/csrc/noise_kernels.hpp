@@ -1,0 +1,143 @@
+// On-device measurement-noise streams, value-compatible with the reference's NoiseProfiler (noise.py:29-207) and hence with
+// numpy.random.Generator(PCG64): SURVEY.md section 8f rank 1.
+//
+// Restated third-party algorithms (numpy is not vendored in the reference; requirements.txt:1 pins numpy==2.2.4):
+//   * PCG64 (numpy/random/src/pcg64/pcg64.h): 128-bit LCG state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc, output
+//     XSL-RR: rotr64(hi ^ lo, hi >> 58) of the *advanced* state; next_double = (u64 >> 11) * 2^-53.  Seeding (SeedSequence +
+//     pcg64_set_seed) happens on the host, vectorised, in pcg.py.
+//   * Generator.uniform(low, high) = low + (high - low) * next_double;  Generator.normal(loc, scale) = loc + scale * z with z
+//     from the 256-layer ziggurat of numpy/random/src/distributions/distributions.c (random_standard_normal): tables
+//     fi / wi / ki shipped in data/ziggurat_normal.npz (tools/extract_ziggurat_tables.py), tail and wedge tests as there.
+// One lane owns one feature *pair* of one trial, because the outlier hold couples the two features of a pair
+// (noise.py:82-116); lanes of a wavefront hold consecutive trials so the trial-fastest output layout is written coalesced.
+#pragma once
+#include "rmckf_device.hpp"
+
+namespace uvs {
+
+struct NoiseArgs {
+    uvs_noise_params np;
+    long long T;
+    const unsigned long long *states;      // [T][n_gen][4]: state_hi, state_lo, inc_hi, inc_lo
+    const double *zig;                     // fi[256], wi[256], ki[256] (ki as raw u64 bits)
+    View out;
+};
+
+struct Pcg64 {
+    unsigned long long sh, sl, ih, il;
+    UVS_DEV void load(const unsigned long long *p) { sh = p[0]; sl = p[1]; ih = p[2]; il = p[3]; }
+    UVS_DEV unsigned long long next64() {
+        const unsigned long long MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
+        unsigned long long lo = sl * ML;
+        unsigned long long hi = __umul64hi(sl, ML) + sl * MH + sh * ML;
+        const unsigned long long nlo = lo + il;
+        hi += ih + (nlo < lo ? 1ULL : 0ULL);
+        sh = hi; sl = nlo;
+        const unsigned long long x = hi ^ nlo;
+        const unsigned rot = (unsigned)(hi >> 58);
+        return (x >> rot) | (x << ((64u - rot) & 63u));
+    }
+    UVS_DEV double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+UVS_DEV double standard_normal(Pcg64 &g, const double *zig) {
+    const double *fi = zig, *wi = zig + 256;
+    const unsigned long long *ki = reinterpret_cast<const unsigned long long *>(zig + 512);
+    const double R = 3.6541528853610087963519472518, INV_R = 0.27366123732975827203338247596;
+    for (;;) {
+        unsigned long long r = g.next64();
+        const int idx = (int)(r & 0xff);
+        r >>= 8;
+        const int sign = (int)(r & 1);
+        const unsigned long long rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * wi[idx];
+        if (sign) x = -x;
+        if (rabs < ki[idx]) return x;                                   // ~99.3 %: inside the layer
+        if (idx == 0) {                                                 // tail
+            for (;;) {
+                const double xx = -INV_R * log1p(-g.next_double());
+                const double yy = -log1p(-g.next_double());
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(R + xx) : R + xx;
+            }
+        } else if ((fi[idx - 1] - fi[idx]) * g.next_double() + fi[idx] < exp(-0.5 * x * x)) {
+            return x;                                                   // wedge
+        }
+    }
+}
+
+// One fresh sample of feature `i` (noise.py:120-207).  gens[]: this feature's main generators (component 0, 1, 2), sel: selector.
+UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const double *zig) {
+    const double HALF_PI = 1.5707963267948966, PI = 3.141592653589793;
+    switch (p.type) {
+        case UVS_NOISE_WHITE: return 0.0 + p.std * standard_normal(gens[0], zig);
+        case UVS_NOISE_UNIFORM: return gens[0].next_double();                              // uniform(): 0 + 1 * u
+        case UVS_NOISE_GAUSSIAN_MIXTURE: {
+            const double u = 0.0 + 1.0 * sel.next_double();
+            if (u > p.rho) return 0.0 + p.std * standard_normal(gens[0], zig);
+            return p.mean + p.std * standard_normal(gens[1], zig);
+        }
+        case UVS_NOISE_GAUSSIAN_BIMODAL: {
+            const double u = 0.0 + 1.0 * sel.next_double();
+            if (u > p.rho) return 0.0 + p.std * standard_normal(gens[0], zig);
+            if (u > p.rho / 2) return p.mean + p.std * standard_normal(gens[1], zig);
+            return -p.mean + p.std * standard_normal(gens[2], zig);
+        }
+        default: break;
+    }
+    // ALPHA_STABLE: Chambers-Mallows-Stuck with the reference's special cases (noise.py:179-205)
+    double x;
+    if (p.alpha == 2.0) {
+        x = 0.0 + p.sqrt2 * standard_normal(gens[0], zig);
+    } else if (p.alpha == 1.0 && p.beta == 0.0) {
+        x = tan(-HALF_PI + PI * gens[0].next_double());
+    } else if (p.alpha == 0.5 && fabs(p.beta) == 1.0) {
+        const double z = 0.0 + 1.0 * standard_normal(gens[0], zig);
+        x = p.beta / (z * z);
+    } else {
+        const double V = -HALF_PI + PI * gens[0].next_double();
+        const double W = -log(0.0 + 1.0 * gens[0].next_double());
+        if (p.beta == 0.0) {
+            x = (sin(p.alpha * V) / pow(cos(V), p.inv_alpha)) * pow(cos(V * p.one_minus_alpha) / W, p.expo);
+        } else if (p.alpha != 1.0) {
+            x = p.cms_S * sin(p.alpha * V + p.cms_B) / pow(cos(V), p.inv_alpha) * pow(cos(p.one_minus_alpha * V - p.cms_B) / W, p.expo);
+        } else {
+            const double sv = HALF_PI + p.beta * V;
+            x = p.two_over_pi * (sv * tan(V) - p.beta * log((W * cos(V)) / sv));
+        }
+    }
+    return (p.alpha == 1.0) ? p.gamma * x + p.shift + p.delta : p.gamma * x + p.delta;
+}
+
+__global__ __launch_bounds__(64) void noise_kernel(const NoiseArgs A) {
+    const uvs_noise_params &p = A.np;
+    const int pairs = p.m / 2;
+    const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= A.T * pairs) return;
+    const int pair = (int)(gid / A.T);                       // trial fastest: a wavefront holds one pair of 64 consecutive trials
+    const long long t = gid % A.T;
+    const int comps = (p.type == UVS_NOISE_GAUSSIAN_MIXTURE) ? 2 : (p.type == UVS_NOISE_GAUSSIAN_BIMODAL ? 3 : 1);
+    const bool has_sel = comps > 1;
+    const int n_gen = comps * p.m + (has_sel ? p.m : 0);
+    Pcg64 g[2][3], sel[2];
+    for (int h = 0; h < 2; ++h) {
+        const int i = 2 * pair + h;
+        for (int c = 0; c < 3; ++c) g[h][c].load(A.states + ((t * n_gen) + i + (c < comps ? c : 0) * p.m) * 4);   // generators[i + c*m], noise.py:134-148
+        sel[h].load(A.states + ((t * n_gen) + (has_sel ? comps * p.m + i : i)) * 4);                              // rhoGenerators[i], noise.py:59
+    }
+    double cur0 = 0.0, cur1 = 0.0;
+    int cnt = 0, cnt_max = 0;                                 // noise_hold_cnt / noise_hold_cnt_max of this pair
+    for (int k = 0; k < p.steps; ++k) {
+        if (cnt >= cnt_max) {                                 // noise.py:83-113
+            cnt = 0;
+            cur0 = draw(p, g[0], sel[0], A.zig);
+            cur1 = draw(p, g[1], sel[1], A.zig);
+            cnt_max = (fabs(cur0) > 20.0 || fabs(cur1) > 20.0) ? p.hold_cnt : 0;
+        } else {
+            ++cnt;                                            // noise.py:114-116
+        }
+        *A.out.at(t, k, 2 * pair) = cur0;
+        *A.out.at(t, k, 2 * pair + 1) = cur1;
+    }
+}
+
+}  // namespace uvs

@@ -203,8 +203,12 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
     double *pq = A.q_out.p ? A.q_out.at(trial, 0, grp * JG) : nullptr;
     double *pd = A.dq_out.p ? A.dq_out.at(trial, 0, grp * JG) : nullptr;
+#ifdef UVS_FIXED_OUTPUTS          // diagnostic: outputs of the bench configuration wired at compile time
+    constexpr bool on_noise = true, on_err = true, on_f = false, on_q = true, on_dq = false;
+#else
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
+#endif
 
     if constexpr (PLANT == UVS_PLANT_DH_PINHOLE) {
         if (lane < N) {

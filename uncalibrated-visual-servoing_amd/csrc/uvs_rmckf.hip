@@ -12,6 +12,7 @@
 #include <cstring>
 #include "rmckf_device.hpp"
 #include "rmckf_tuned.hpp"
+#include "noise_kernels.hpp"
 
 namespace uvs {
 
@@ -493,6 +494,16 @@ int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const do
     hipLaunchKernelGGL(uvs::stats_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)T, K, m,
                        uvs::to_view(err), t, k_done, stats);
     return check_launch("stats_kernel");
+}
+
+int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream) {
+    if (!np || T <= 0 || !states || !zig || !out.base) return fail(UVS_ERR_ARG, "%s", "bad noise_generate arguments");
+    if (np->m <= 0 || np->m % 2 || np->m > UVS_MAX_M || np->steps < 0) return fail(UVS_ERR_ARG, "%s", "noise: m must be even and <= UVS_MAX_M");
+    if (np->type < UVS_NOISE_WHITE || np->type > UVS_NOISE_UNIFORM) return fail(UVS_ERR_ARG, "%s", "unknown noise type");
+    uvs::NoiseArgs A{*np, (long long)T, (const unsigned long long *)states, zig, uvs::to_view(out)};
+    const long long lanes = (long long)T * (np->m / 2);
+    hipLaunchKernelGGL(uvs::noise_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    return check_launch("noise_kernel");
 }
 
 int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
