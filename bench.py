@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--trials', type=int, default=TRIALS_PER_GPU, help='trials per GPU (default = BASELINE config 2)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
     ap.add_argument('--layout', default='kct', choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams')
     args = ap.parse_args()
@@ -148,11 +149,15 @@ def main():
         gen_s = time.perf_counter() - t0
 
     import torch
+    local_rank %= max(1, torch.cuda.device_count())              # gloo test mode: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as td
-        td.init_process_group('nccl', device_id=dev)             # RCCL over xGMI
+        if args.backend == 'nccl':
+            td.init_process_group('nccl', device_id=dev)         # RCCL over xGMI
+        else:
+            td.init_process_group('gloo')
     uvs_amd.lib()
 
     t0 = time.perf_counter()
@@ -189,11 +194,13 @@ def main():
             k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         uvs_amd._lib.check(rc)
 
+    def gather():
+        rows = dist.pack_rows(stats, status)
+        return dist.gather_trial_rows(rows if args.backend == 'nccl' else rows.cpu(), len(plan))
+
     def one_step():
         launch()
-        if world > 1:
-            return dist.gather_trial_rows(dist.pack_rows(stats, status), len(plan))
-        return None
+        return gather() if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -211,19 +218,21 @@ def main():
         launch()
         e1.record()
         if world > 1:
-            dist.gather_trial_rows(dist.pack_rows(stats, status), len(plan))
+            gathered = gather()
         kernel_ms.append((e0, e1))
     barrier()
     wall = time.perf_counter() - t0
+    red_dev = dev if args.backend == 'nccl' else torch.device('cpu')
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        w = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         td.all_reduce(w, op=td.ReduceOp.MAX)
         wall = float(w.item())
+        assert gathered.shape == (len(plan), 4)
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_ms]
 
     updates_per_launch = int(k_done.sum().item())                 # FAIL trials stop early; count what was actually computed
     if world > 1:
-        u = torch.tensor([updates_per_launch], dtype=torch.int64, device=dev)
+        u = torch.tensor([updates_per_launch], dtype=torch.int64, device=red_dev)
         td.all_reduce(u)
         total_updates = int(u.item())
     else:
