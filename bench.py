@@ -113,7 +113,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--trials', type=int, default=TRIALS_PER_GPU, help='trials per GPU (default = BASELINE config 2)')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 5], help='BASELINE.json config: 2 (headline), 3 (mixture + annealing, 262144 trials), 5 (16-feature / 7-DoF stress)')
+    ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
+    ap.add_argument('--trials', type=int, default=0, help='trials per GPU (default: the size BASELINE.json names for the config)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
@@ -130,8 +132,15 @@ def main():
     from uvs_amd import batch, dist, engine
 
     cfg = config2()
+    if args.trials == 0:
+        args.trials = 262144 if args.config == 3 else TRIALS_PER_GPU
+    cell = ALPHA
+    if args.config == 3:                                          # BASELINE config 3 / BASELINE.md table
+        cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0, 'rho': 0.1}, hold=bool(args.hold), hold_time=0.5)
+        cfg['estimator']['estimator_params']['annealing'] = True
+        cell = 0.1
     cfg['experiments']['epoch'] = args.trials * world
-    plan = batch.plan_trials(cfg, cells=[ALPHA])                  # global enumeration: trial t -> seed 123456 + t, jitter draw t
+    plan = batch.plan_trials(cfg, cells=[cell])                   # global enumeration: trial t -> seed 123456 + t, jitter draw t
     lo, hi = dist.shard_range(len(plan), rank, world)
     t_log = engine.loop_clock(0.05, 15)
     K = len(t_log)
@@ -140,7 +149,8 @@ def main():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     workers = max(1, cores // max(1, world))
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    assert not (args.host_noise and args.config != 2), '--host-noise is wired for config 2 only'
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         cpu = cpu_baseline(plan.q_start)
     noise_host, gen_s = None, 0.0
     if args.host_noise:
@@ -161,25 +171,41 @@ def main():
     uvs_amd.lib()
 
     t0 = time.perf_counter()
-    if args.host_noise:
-        noise = torch.as_tensor(noise_host, device=dev)           # PCIe upload, outside the timed region
-    else:                                                         # NoiseProfiler-compatible streams generated on the GPU
-        noise = batch.device_noise(cfg, plan, lo, hi, K, dev)
-        torch.cuda.synchronize()
-        gen_s = time.perf_counter() - t0
-    if args.layout != 'kct':                                      # noise_host is [step][comp][trial]
-        noise = noise.permute({'ktc': (0, 2, 1), 'tkc': (2, 0, 1)}[args.layout]).contiguous()
-    q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
+    noise = None
+    if args.config != 5:
+        if args.host_noise:
+            noise = torch.as_tensor(noise_host, device=dev)       # PCIe upload, outside the timed region
+        else:                                                     # NoiseProfiler-compatible streams generated on the GPU
+            noise = batch.device_noise(cfg, plan, lo, hi, K, dev)
+            torch.cuda.synchronize()
+            gen_s = time.perf_counter() - t0
+        if args.layout != 'kct':                                  # generated as [step][comp][trial]
+            noise = noise.permute({'ktc': (0, 2, 1), 'tkc': (2, 0, 1)}[args.layout]).contiguous()
+        q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
     torch.cuda.synchronize()
     h2d_s = time.perf_counter() - t0
     del noise_host
 
     p = cfg['estimator']['estimator_params']
-    fp = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
-    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    M, N, x0 = 8, 6, None
+    if args.config == 5:                                          # synthetic 16-feature / 7-DoF stress shape on the consistent linear plant
+        M, N = 32, 7
+        lin = uvs_amd.LinearPlant.random(M, N, seed=2)
+        rng = np.random.default_rng(5)
+        q_goal = lin.q0 + rng.uniform(-0.3, 0.3, N)
+        desired = lin.features(q_goal)
+        gq = np.random.default_rng(12345)
+        q0 = torch.as_tensor(q_goal + gq.uniform(-0.15, 0.15, (len(plan), N))[lo:hi], device=dev)
+        x0 = torch.as_tensor(np.tile((lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel(), (hi - lo, 1)), device=dev)
+        noise = uvs_amd.noise_device.generate(uvs_amd.NoiseType.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), plan.seed[lo:hi], M, K, device=dev)
+        fp = engine.make_params(M, N, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, desired, False, args.lanes)
+        plant = lin.to_struct(dev)
+    else:
+        fp = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+        plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
     T = hi - lo
     # output buffers are allocated once and reused by every step (engine.closed_loop allocates; here we pre-allocate by hand)
-    bufs = {k: engine.alloc_stream(T, K, c, args.layout, dev, zero=True) for k, c in (('x', 48), ('err', 8), ('q', 6))}
+    bufs = {k: engine.alloc_stream(T, K, c, args.layout, dev, zero=True) for k, c in (('x', M * N), ('err', M), ('q', N))}
     stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
     status = torch.zeros(T, dtype=torch.int32, device=dev)
     k_done = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -189,7 +215,7 @@ def main():
 
     def launch():
         rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV, engine.stream_view(bufs['x'], args.layout),
+            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV if x0 is None else flat(x0), engine.stream_view(bufs['x'], args.layout),
             engine.stream_view(bufs['err'], args.layout), engine.stream_view(bufs['q'], args.layout), NV, NV, stats.data_ptr(), status.data_ptr(),
             k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         uvs_amd._lib.check(rc)
@@ -240,22 +266,24 @@ def main():
     value = total_updates * args.steps / wall
 
     if rank == 0:
-        b_alg = 8 * (2 * 8 + 6 + 8 * 6)                           # 560 B / update: noise in, err + X + q out
+        b_alg = 8 * (2 * M + N + M * N)                           # 560 B / update at (8,6): noise in, err + X + q out
         avg_ms = float(np.mean(kernel_ms))
         achieved = updates_per_launch * b_alg / (avg_ms * 1e-3) / 1e9
         traffic = None
         tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tr_path):
-            traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')
+        if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
+            traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')     # rocprofv3 PMC, measured on exactly this launch shape
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, '
+            'config': {'workload': {2: 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, ',
+                                    3: f'BASELINE config 3: 4-feature UR10 closed loop, GMCKF(RMCKF) annealed sigma, Gaussian mixture rho=0.1 mean=50 hold={bool(args.hold)}, ',
+                                    5: 'BASELINE config 5: synthetic 16-feature / 7-DoF (m=32, n=7) linear plant, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5, '}[args.config] +
                                    f'{T} trials/GPU x {K} updates, X+err+q logged per step', 'trials_per_gpu': T, 'updates_per_trial': K,
-                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0], 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
+                       'lanes_per_filter': args.lanes or engine.supported_lanes(M, N)[0], 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'closed_loop_kernel<8,6,L>', 'avg_kernel_ms': avg_ms,
+                         'traffic': traffic, 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
             'cpu_baseline': cpu,
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
