@@ -1,0 +1,69 @@
+"""Monte-Carlo driver on the GPU: the reference's 12-cell sweep, statistics per cell, results.csv in the reference's format."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def uvs():
+    import uvs_amd
+    return uvs_amd
+
+
+def _cfg(method='GMCKF', epoch=20):
+    cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'config_reference.json')))
+    cfg['estimator']['method'] = method
+    cfg['experiments']['epoch'] = epoch
+    return cfg
+
+
+def test_sweep_of_the_reference_config(uvs):
+    """main.py's experiment: 12 alphas x epoch trials.  Heavier tails must cost more ITAE; alpha = 2 sits at the level of the
+    paper's figure (results/results1.fig: RMCKF 22 494 +- 2 709 at alpha = 2 on the real simulator)."""
+    res = uvs.batch.run_batch(_cfg(epoch=64), want=('err',))
+    assert len(res.plan) == 768 and res.stats.shape == (768, 3)
+    s = uvs.stats.cell_summary(res.stats.cpu().numpy(), res.status.cpu().numpy(), res.plan.cell)
+    itae = np.array([s[c]['itae_median'] for c in range(12)])
+    assert all(s[c]['success'] == 64 for c in range(12))
+    assert itae[0] > 2 * itae[-1] and np.all(np.diff(itae[[0, 3, 6, 9, 11]]) < 0)
+    assert 1.5e4 < s[11]['itae_mean'] < 4e4
+    # statistics are those of the error stream
+    t = uvs.engine.loop_clock(0.05, 15)
+    again = uvs.engine.stats_reduce(res.streams['err'], t, res.k_done).cpu().numpy()
+    assert rel_err(again, res.stats.cpu().numpy()) <= 1e-12
+
+
+def test_first_trial_of_the_sweep_is_the_reference_trial(uvs):
+    """Trial 0 of the sweep = alpha 1.0, seed 123456, first jitter draw: the same trial run through Experiment.run()."""
+    cfg = _cfg(epoch=2)
+    res = uvs.batch.run_batch(cfg, want=('err', 'q'), noise_on_device=False)
+    prof = uvs.NoiseProfiler(8, uvs.NoiseType.ALPHA_STABLE, seed=123456, noise_params=dict(cfg['noise']['noise_params'], alpha=1.0))
+    ex = uvs.Experiment(res.plan.q_start[0], cfg['experiments']['desired_f'], prof, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.GMCKF,
+                        method_params=cfg['estimator']['estimator_params'])
+    status, t, err, q, *_ = ex.run()
+    assert np.array_equal(res.streams['err'].cpu().numpy()[:, :, 0], err) and np.array_equal(res.streams['q'].cpu().numpy()[:, :, 0], q)
+
+
+def test_results_csv_has_the_reference_format(uvs, tmp_path):
+    import pandas as pd
+    cfg = _cfg(epoch=1)
+    res = uvs.batch.run_batch(cfg, cells=[1.5, 2.0], want=('err', 'q', 'f'))
+    path = tmp_path / 'results.csv'
+    uvs.batch.write_results_csv(res, cfg, uvs.SyntheticPlant.ur10(cfg['experiments']['desired_f']), str(path))
+    df = pd.read_csv(path)
+    assert list(df.columns) == uvs.batch.CSV_COLUMNS and len(df) == 2 * 299
+    assert set(df['status']) == {'ExperimentStatus.SUCCESS'} and set(df['experiment_id']) == {0, 1} and set(df['kernel_bw']) == {-1.0}
+    first = df[df.experiment_id == 0]
+    assert np.allclose(first['t'].values, uvs.engine.loop_clock(0.05, 15)) and np.allclose(first['rho'].values, 1.5)
+    f = first[[f'f_{i}' for i in range(1, 9)]].values
+    d = first[[f'desired_f_{i}' for i in range(1, 9)]].values
+    assert np.allclose(f - d, res.streams['err'].cpu().numpy()[:, :, 0], rtol=0, atol=1e-9)
+    # the MATLAB post-processing recomputes the statistics from these columns (results/plot_errorbar.m:39-84)
+    from oracle.rmckf_dense import trial_stats
+    assert rel_err(trial_stats(d - f, first['t'].values), res.stats.cpu().numpy()[0]) <= 1e-9
