@@ -68,6 +68,9 @@ typedef struct uvs_filter_params {
     double gain;                /* ibvs_gain lambda (:26, :312)                                     */
     double dt;                  /* t_s (:24)                                                        */
     double reg;                 /* 0.001**2 added to Cy before inversion (:280)                     */
+    double fpi_threshold;       /* MCKF fixed-point stop test (:38, :215)                           */
+    int32_t fpi_epoch_max;      /* MCKF iteration cap; reaching it skips the correction (:39, :246) */
+    int32_t reserved;
     double desired[UVS_MAX_M];  /* desired_f (:21)                                                  */
 } uvs_filter_params;
 

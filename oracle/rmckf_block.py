@@ -15,14 +15,16 @@ run ((2, 6), (32, 7), ...; experiment.py:54,170-177 hard-wire m = 8, n = 6).
 """
 import numpy as np
 
-KF, IMCCKF, GMCKF = 'KF', 'IMCCKF', 'GMCKF'
+KF, MCKF, IMCCKF, GMCKF = 'KF', 'MCKF', 'IMCCKF', 'GMCKF'
 REG = 0.001 ** 2                                                    # experiment.py:280
 
 
 class BlockFilter:
-    def __init__(self, m, n, x0=None, method=GMCKF, kernel_bw=10.0, annealing=False, k_max=300):
+    def __init__(self, m, n, x0=None, method=GMCKF, kernel_bw=10.0, annealing=False, k_max=300, fpi_threshold=0.1, fpi_epoch_max=1000):
         self.m, self.n, self.method = m, n, method
         self.kernel_bw, self.annealing, self.k_max = kernel_bw, annealing, k_max
+        self.fpi_threshold, self.fpi_epoch_max = fpi_threshold, fpi_epoch_max
+        self.fpi_iterations = 0
         self.X = np.zeros((m, n)) if x0 is None else np.array(x0, float).reshape(m, n)
         self.P = np.tile(np.eye(n), (m, 1, 1))
         self.first = True
@@ -34,6 +36,8 @@ class BlockFilter:
         h = np.zeros(n) if self.first else np.asarray(dq_prev, float).ravel()
         self.first = False
         P = self.P + np.eye(n)                                      # predict
+        if self.method == MCKF:
+            return self._step_mckf(P, Z, h, k)
         nu = Z - self.X @ h                                         # innovation, row by row
         g = P @ h                                                   # (m, n)
         a = g @ h                                                   # h^T P_i h
@@ -57,6 +61,43 @@ class BlockFilter:
         self.P = A @ P @ np.transpose(A, (0, 2, 1)) + kk[:, :, None] * kk[:, None, :]
         return kappa
 
+    def _step_mckf(self, P, Z, h, k):
+        """Fixed-point MCKF (experiment.py:194-250) in block form.  With B = blkdiag(chol(P), chol(R)) block diagonal,
+        D - W X_c = [L_i^-1 (x_i - xc_i); z_i - h.xc_i]; P_hat_i = L_i Cx_i^-1 L_i^T, R_hat_i = 1/Cy_i; the stop test uses the
+        norm over all rows (:244) and a zero in Cy (8x8 matrix, :231) or max epoch (:246-248) skips the whole correction."""
+        m, n = self.m, self.n
+        self.sigma = bw = self._sigma(k)
+        Lc = np.linalg.cholesky(P)                                  # (m, n, n) lower factors
+        X = self.X
+        nu0 = Z - X @ h                                             # Z - H X: the gain is applied to the *prior* innovation (:242)
+        Xc, diff, it, skip = X.copy(), np.inf, 0, False
+        kk = np.zeros((m, n))
+        while diff > self.fpi_threshold and it < self.fpi_epoch_max:
+            ex = np.linalg.solve(Lc, (X - Xc)[:, :, None])[:, :, 0]    # L_i^-1 (x_i - xc_i)
+            ez = Z - Xc @ h
+            cx = np.exp(-0.5 * ex ** 2 / bw ** 2)
+            cy = np.exp(-0.5 * ez ** 2 / bw ** 2)
+            if np.any(cy == 0.0):                                   # inv(Cy) raises LinAlgError (:231-236)
+                skip = True
+                break
+            P_hat = Lc @ (np.transpose(Lc, (0, 2, 1)) / cx[:, :, None])
+            g = P_hat @ h
+            kk = g / ((g @ h) + 1.0 / cy)[:, None]
+            Xc_old = Xc
+            Xc = X + kk * nu0[:, None]
+            diff = np.linalg.norm(Xc - Xc_old) / np.linalg.norm(Xc_old)
+            it += 1
+            if it == self.fpi_epoch_max:
+                skip = True
+        self.fpi_iterations = it
+        if not skip:
+            self.X = Xc
+            A = np.eye(n)[None] - kk[:, :, None] * h[None, None, :]
+            self.P = A @ P @ np.transpose(A, (0, 2, 1)) + kk[:, :, None] * kk[:, None, :]
+        else:
+            self.P = P
+        return np.ones(m)
+
     def _sigma(self, k):
         return self.kernel_bw + 100 * (1 - k / self.k_max) if self.annealing else self.kernel_bw
 
@@ -66,17 +107,18 @@ def control_law(X, err, kappa, gain):
     return -gain * (np.linalg.pinv(X) @ (kappa * err))
 
 
-def run_replay(f_seq, dq_seq, x0, desired_f, gain, method=GMCKF, kernel_bw=10.0, annealing=False, k_max=300):
+def run_replay(f_seq, dq_seq, x0, desired_f, gain, method=GMCKF, kernel_bw=10.0, annealing=False, k_max=300, fpi_threshold=0.1,
+               fpi_epoch_max=1000):
     f_seq, dq_seq = np.asarray(f_seq, float), np.asarray(dq_seq, float)
     K, m, n = len(dq_seq), f_seq.shape[1], dq_seq.shape[1]
-    filt = BlockFilter(m, n, x0, method, kernel_bw, annealing, k_max)
-    Xs, errs, kaps, cmds = [], [], [], []
+    filt = BlockFilter(m, n, x0, method, kernel_bw, annealing, k_max, fpi_threshold, fpi_epoch_max)
+    Xs, errs, kaps, cmds, its = [], [], [], [], []
     for k in range(K):
         kappa = filt.step(f_seq[k + 1] - f_seq[k], dq_seq[k], k)
         err = f_seq[k + 1] - np.asarray(desired_f, float)
         cmds.append(control_law(filt.X, err, kappa, gain))
-        Xs.append(filt.X.ravel().copy()); errs.append(err); kaps.append(kappa.copy())
-    return dict(X=np.array(Xs), err=np.array(errs), kappa=np.array(kaps), dq_cmd=np.array(cmds), P_final=filt.P.copy())
+        Xs.append(filt.X.ravel().copy()); errs.append(err); kaps.append(kappa.copy()); its.append(filt.fpi_iterations)
+    return dict(X=np.array(Xs), err=np.array(errs), kappa=np.array(kaps), dq_cmd=np.array(cmds), P_final=filt.P.copy(), fpi_iterations=np.array(its))
 
 
 def run_closed_loop(plant, q_start, desired_f, noise_seq, t_s, t_max, gain, x0, method=GMCKF,

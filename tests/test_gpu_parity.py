@@ -8,7 +8,7 @@ from conftest import golden_names, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
-CLOSED = [n for n in golden_names('closed_') if '_mckf_' not in n]          # KF / IMCCKF / GMCKF fixtures
+CLOSED = golden_names('closed_')                                             # KF / MCKF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
 LANES_86 = (1, 2, 4, -1, -2, -4, 8)      # 1, 2, 4: tuned kernel (closed loop); negative: generic template with |L| lanes
 
@@ -30,7 +30,7 @@ def _cuda(a):
 def _fp(uvs, g, lanes=0, steps=None, **kw):
     meta, p = g['meta'], g['meta']['params']
     return uvs.engine.make_params(8, 6, meta['method'], p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'],
-                                  g['desired'], p['initial_guess'], lanes, steps, **kw)
+                                  g['desired'], p['initial_guess'], lanes, steps, p['fpi_threshold'], p['fpi_epoch_max'], **kw)
 
 
 # ---------------------------------------------------------------------------------------------- open-loop replay
@@ -99,7 +99,7 @@ def test_initial_guess_matches_reference(uvs):
 
 
 # ---------------------------------------------------------------------------------------------- drop-in API
-@pytest.mark.parametrize('name', ['closed_gmckf_a1p5', 'closed_gmckf_mix_anneal', 'closed_kf_a2p0', 'closed_imcckf_a1p5'])
+@pytest.mark.parametrize('name', ['closed_gmckf_a1p5', 'closed_gmckf_mix_anneal', 'closed_kf_a2p0', 'closed_imcckf_a1p5', 'closed_mckf_a1p5'])
 def test_experiment_api_drop_in(uvs, name):
     """Experiment(...).run() with the reference's call signature returns the reference's 9-tuple."""
     g = load_golden(name)
@@ -115,7 +115,7 @@ def test_experiment_api_drop_in(uvs, name):
     assert np.array_equal(t, g['t']) and np.array_equal(noise, g['noise'])
     for got, ref in ((err, g['err']), (q, g['q']), (f, g['f']), (cam, g['cam'])):
         assert got.shape == ref.shape and rel_err(got, ref) <= 1e-8
-    assert np.array_equal(fd, np.tile(g['desired'], (len(t), 1))) and np.all(bw == -1)
+    assert np.array_equal(fd, np.tile(g['desired'], (len(t), 1))) and np.array_equal(bw, g['sigma_log'])
 
 
 def test_experiment_api_with_external_robot(uvs):
@@ -132,10 +132,26 @@ def test_experiment_api_with_external_robot(uvs):
     assert rel_err(err, g['err']) <= 1e-8 and rel_err(q, g['q']) <= 1e-8 and rel_err(cam, g['cam']) <= 1e-8
 
 
-def test_mckf_is_refused_loudly(uvs):
+def test_analytical_is_refused_loudly(uvs):
     with pytest.raises(NotImplementedError):
-        uvs.Experiment([0] * 6, [0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.MCKF, initial_guess=True,
-                       kernel_bw=10, fpi_threshold=0.1, fpi_epoch_max=10, annealing=False).run()
+        uvs.Experiment([0] * 6, [0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.ANALYTICAL).run()
+
+
+@pytest.mark.parametrize('lanes', [-1, -2, 4, 8])
+def test_mckf_fixed_point_iterations_match_block_oracle(uvs, lanes):
+    """A tight threshold forces several fixed-point passes (Cholesky factor, Cx != I) and an epoch cap that skips corrections."""
+    from oracle import rmckf_block
+    g = load_golden('closed_mckf_a1p5')
+    meta = g['meta']
+    K = 120
+    f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+    for thr, cap in ((1e-9, 1000), (1e-3, 2)):
+        fp = uvs.engine.make_params(8, 6, 'MCKF', 5.0, True, meta['dt'], meta['t_max'], meta['gain'], g['desired'], True, lanes, K, thr, cap)
+        out = uvs.engine.replay(fp, _cuda(f_seq[:, :, None]), _cuda(g['dq_prev'][:K, :, None]), _cuda(g['X'][0][None]), final_state=True)
+        ref = rmckf_block.run_replay(f_seq, g['dq_prev'][:K], g['X'][0], g['desired'], meta['gain'], 'MCKF', 5.0, True, 300, thr, cap)
+        assert ref['fpi_iterations'].max() >= 2
+        assert rel_err(out['x'].cpu().numpy()[:, :, 0], ref['X']) <= 1e-9
+        assert rel_err(out['p_final'].cpu().numpy()[0].reshape(8, 6, 6), ref['P_final']) <= 1e-9
 
 
 # ---------------------------------------------------------------------------------------------- other shapes

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol(uvs):
 def test_struct_layouts_match_the_header(uvs):
     # sizes implied by include/uvs_rmckf.h (LP64): catches a drifted ctypes mirror before it corrupts a launch
     assert ctypes.sizeof(uvs._lib.View) == 32
-    assert ctypes.sizeof(uvs._lib.FilterParams) == 8 * 4 + 5 * 8 + 32 * 8
+    assert ctypes.sizeof(uvs._lib.FilterParams) == 8 * 4 + 5 * 8 + 8 + 2 * 4 + 32 * 8
     assert ctypes.sizeof(uvs._lib.Plant) == 8 + 5 * 8 * 8 + 16 * 3 * 8 + 16 + 8 + 24
 
 
@@ -42,7 +42,8 @@ def test_argument_errors_are_reported_not_thrown(uvs):
     fp = uvs.engine.make_params(5, 3, 'GMCKF', desired=np.zeros(5), steps=3)          # shape that is not instantiated
     rc = lib.uvs_rmckf_replay_f64(ctypes.byref(fp), 4, V, V, V, V, V, V, V, None, None, V, V, None)
     assert rc == -2
-    fp = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), steps=3)
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8), steps=3)
+    fp.method = 1                                                                      # ANALYTICAL is not an estimator
     rc = lib.uvs_rmckf_replay_f64(ctypes.byref(fp), 4, V, V, V, V, V, V, V, None, None, V, V, None)
     assert rc == -4
     assert lib.uvs_supported_lanes(8, 6, None, 0) >= 4 and lib.uvs_supported_lanes(7, 7, None, 0) == 0
@@ -62,6 +63,8 @@ def test_no_gpu_means_no_result(uvs):
     with pytest.raises(uvs.UvsLibraryError):
         uvs.Experiment([0.0] * 6, [0.0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.GMCKF, initial_guess=True,
                        kernel_bw=10, fpi_threshold=0.1, fpi_epoch_max=10, annealing=False).run()
+    with pytest.raises(NotImplementedError):
+        uvs.Experiment([0.0] * 6, [0.0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.ANALYTICAL).run()
 
 
 def test_product_never_imports_the_oracle():

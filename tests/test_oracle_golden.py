@@ -63,14 +63,15 @@ def test_dense_restatement_reproduces_reference(name):
     assert np.array_equal(out['dq'][:-1], g['dq_prev'][1:]) or rel_err(out['dq'][:-1], g['dq_prev'][1:]) <= tol
 
 
-@pytest.mark.parametrize('name', [n for n in CLOSED if 'mckf_a' not in n or 'imcckf' in n or 'gmckf' in n])
+@pytest.mark.parametrize('name', CLOSED)
 def test_block_replay_matches_reference(name):
     """Open-loop replay of the reference's recorded streams through the per-row form: no feedback, tight gate."""
     g = load_golden(name)
     meta, p = g['meta'], g['meta']['params']
     f_seq = np.vstack([g['f_init'][None], g['f']])
     out = rmckf_block.run_replay(f_seq, g['dq_prev'], g['X'][0], g['desired'], meta['gain'], method=meta['method'],
-                                 kernel_bw=p['kernel_bw'], annealing=p['annealing'], k_max=int(meta['t_max'] / meta['dt']))
+                                 kernel_bw=p['kernel_bw'], annealing=p['annealing'], k_max=int(meta['t_max'] / meta['dt']),
+                                 fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'])
     assert rel_err(out['X'][g['X_steps']], g['X']) <= 1e-11
     assert np.array_equal(out['err'], g['err'])
     # commanded dq of step k is the regressor of step k+1

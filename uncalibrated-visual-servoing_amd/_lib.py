@@ -34,7 +34,8 @@ class FilterParams(C.Structure):
     _fields_ = [('m', C.c_int32), ('n', C.c_int32), ('method', C.c_int32), ('annealing', C.c_int32), ('k_max', C.c_int32),
                 ('steps', C.c_int32), ('initial_guess', C.c_int32), ('lanes_per_filter', C.c_int32),
                 ('kernel_bw', C.c_double), ('anneal_span', C.c_double), ('gain', C.c_double), ('dt', C.c_double),
-                ('reg', C.c_double), ('desired', C.c_double * UVS_MAX_M)]
+                ('reg', C.c_double), ('fpi_threshold', C.c_double), ('fpi_epoch_max', C.c_int32), ('reserved', C.c_int32),
+                ('desired', C.c_double * UVS_MAX_M)]
 
 
 class NoiseParams(C.Structure):

@@ -127,15 +127,16 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
     cfg = load_config(cfg)
     ex, est = cfg['experiments'], cfg['estimator']
     method = Method[est['method']]
-    if method not in (Method.KF, Method.IMCCKF, Method.GMCKF):
-        raise NotImplementedError(f'{method.name} is not on the HIP path (KF, IMCCKF, GMCKF are)')
+    if method == Method.ANALYTICAL:
+        raise NotImplementedError('ANALYTICAL is not an estimator (and crashes in the reference: R is unbound, experiment.py:121)')
     plant = SyntheticPlant.ur10(ex['desired_f']) if plant is None else plant
     plan = plan_trials(cfg, cells, epoch)
     lo, hi = dist.shard_range(len(plan), rank, world)
     p = est['estimator_params']
     m, n = len(ex['desired_f']), plant.n_joints
     fp = engine.make_params(m, n, method.name, p.get('kernel_bw', 1.0), p.get('annealing', False), ex['dt'], ex['t_max'],
-                            ex['ibvs_gain'], ex['desired_f'], p['initial_guess'], lanes)
+                            ex['ibvs_gain'], ex['desired_f'], p['initial_guess'], lanes, None, p.get('fpi_threshold', 0.1),
+                            p.get('fpi_epoch_max', 1000))
     t_log = engine.loop_clock(ex['dt'], ex['t_max'])
     K, Tl = len(t_log), hi - lo
     dev = torch.device(device)

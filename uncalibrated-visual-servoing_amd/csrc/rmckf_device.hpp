@@ -119,6 +119,10 @@ struct Rows {
     //   Joseph with R = 1 collapses to the symmetric rank-1 downdate P_i -= gamma (2 - gamma (a + 1)) g g^T.
     // kap[] receives the correntropy weights kappa_i that the control law re-uses (experiment.py:308).
     UVS_DEV void update(const uvs_filter_params &fp, const double (&z)[R], const double (&h)[N], double sigma, double (&kap)[R]) {
+        if (fp.method == UVS_METHOD_MCKF) {
+            update_mckf(fp, z, h, sigma, kap);
+            return;
+        }
         double nu[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -170,6 +174,156 @@ struct Rows {
                 const double w = beta * g[l];
 #pragma unroll
                 for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = fma(-w, g[j], p[r][Sym<N>::at(l, j)]);
+            }
+        }
+    }
+
+    // Fixed-point MCKF (experiment.py:194-250) row by row.  B = blkdiag(chol(P), chol(R)) is block diagonal, hence
+    //   D - W X_c = [ L_i^-1 (x_i - xc_i) ;  z_i - h.xc_i ],   P_hat_i = L_i Cx_i^-1 L_i^T,   R_hat_i = 1 / Cy_i,
+    //   k_i = P_hat_i h / (h.P_hat_i h + R_hat_i),   xc_i <- x_i + k_i (z_i - h.x_i)              (the prior innovation, :242)
+    // iterated until ||Xc - Xc_old|| / ||Xc_old|| <= fpi_threshold over ALL rows (:244).  A zero in Cy makes inv(Cy) raise
+    // and the epoch cap is reached -> the whole correction (X and P) is skipped (:231-236, :246-250).  The first pass has
+    // Xc = X, so Cx = I and P_hat = P: no factorisation is needed unless a second pass is.  Joseph (:297) with a gain that is
+    // not gamma * P h is the rank-2 form P - k g^T - g k^T + (h.g + 1) k k^T with g = P h.
+    UVS_DEV void update_mckf(const uvs_filter_params &fp, const double (&z)[R], const double (&h)[N], double sigma, double (&kap)[R]) {
+        double nu0[R], gp[R][N], ap[R], xc[R][N], kk[R][N];
+        int bad = 0;
+        double num = 0.0, den = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            kap[r] = 1.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) p[r][Sym<N>::at(l, l)] += 1.0;           // predict (experiment.py:167)
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(x[r][j], h[j], acc);
+            nu0[r] = z[r] - acc;
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) s = fma(p[r][Sym<N>::at(l, j)], h[j], s);
+                gp[r][l] = s;
+                a = fma(h[l], s, a);
+            }
+            ap[r] = a;
+            const double cy = gaussian_kernel(nu0[r], sigma);                    // first pass: Xc = X
+            bad |= (cy == 0.0);
+            const double gain = 1.0 / (a + 1.0 / cy);
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                kk[r][l] = gp[r][l] * gain;
+                xc[r][l] = fma(kk[r][l], nu0[r], x[r][l]);
+                const double d = xc[r][l] - x[r][l];
+                num = fma(d, d, num);
+                den = fma(x[r][l], x[r][l], den);
+            }
+        }
+        bool skip = group_or<L>(bad) != 0;
+        double diff = sqrt(group_sum<L>(num)) / sqrt(group_sum<L>(den));
+        int it = 1;
+        if (it == fp.fpi_epoch_max) skip = true;
+        bool more = !skip && (diff > fp.fpi_threshold) && it < fp.fpi_epoch_max;  // NaN diff ends the loop like the reference's while
+        if (__any(more)) {
+            double Lc[R][Sym<N>::NP];                                            // lower Cholesky factors of the predicted blocks, packed
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double dsum = p[r][Sym<N>::at(j, j)];
+#pragma unroll
+                    for (int k2 = 0; k2 < j; ++k2) dsum = fma(-Lc[r][Sym<N>::at(k2, j)], Lc[r][Sym<N>::at(k2, j)], dsum);
+                    const double ljj = sqrt(dsum);
+                    Lc[r][Sym<N>::at(j, j)] = ljj;
+#pragma unroll
+                    for (int i = j + 1; i < N; ++i) {
+                        double s = p[r][Sym<N>::at(j, i)];
+#pragma unroll
+                        for (int k2 = 0; k2 < j; ++k2) s = fma(-Lc[r][Sym<N>::at(k2, i)], Lc[r][Sym<N>::at(k2, j)], s);
+                        Lc[r][Sym<N>::at(j, i)] = s / ljj;                       // L[i][j], stored at packed (j, i)
+                    }
+                }
+            }
+            while (__any(more)) {
+                int bad2 = 0;
+                double num2 = 0.0, den2 = 0.0;
+                double xn[R][N], kn[R][N];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double ex[N], t[N], g[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {                                // L ex = x - xc (forward substitution)
+                        double s = x[r][i] - xc[r][i];
+#pragma unroll
+                        for (int k2 = 0; k2 < i; ++k2) s = fma(-Lc[r][Sym<N>::at(k2, i)], ex[k2], s);
+                        ex[i] = s / Lc[r][Sym<N>::at(i, i)];
+                    }
+                    double ez = z[r];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ez = fma(-xc[r][j], h[j], ez);
+                    const double cy = gaussian_kernel(ez, sigma);
+                    bad2 |= (cy == 0.0);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {                                // t = Cx^-1 L^T h
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = j; i < N; ++i) s = fma(Lc[r][Sym<N>::at(j, i)], h[i], s);
+                        t[j] = s / gaussian_kernel(ex[j], sigma);
+                    }
+                    double a = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {                                // g = L t = P_hat h
+                        double s = 0.0;
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) s = fma(Lc[r][Sym<N>::at(j, i)], t[j], s);
+                        g[i] = s;
+                        a = fma(h[i], s, a);
+                    }
+                    const double gain = 1.0 / (a + 1.0 / cy);
+#pragma unroll
+                    for (int l = 0; l < N; ++l) {
+                        kn[r][l] = g[l] * gain;
+                        xn[r][l] = fma(kn[r][l], nu0[r], x[r][l]);
+                        const double d = xn[r][l] - xc[r][l];
+                        num2 = fma(d, d, num2);
+                        den2 = fma(xc[r][l], xc[r][l], den2);
+                    }
+                }
+                const bool hit_zero = group_or<L>(bad2) != 0;
+                const double diff2 = sqrt(group_sum<L>(num2)) / sqrt(group_sum<L>(den2));
+                if (more) {                                                      // filters that already stopped keep their result
+                    if (hit_zero) {
+                        skip = true;
+                        more = false;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int l = 0; l < N; ++l) { xc[r][l] = xn[r][l]; kk[r][l] = kn[r][l]; }
+                        ++it;
+                        if (it == fp.fpi_epoch_max) skip = true;
+                        more = !skip && (diff2 > fp.fpi_threshold) && it < fp.fpi_epoch_max;
+                    }
+                }
+            }
+        }
+        if (!skip) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double c2 = ap[r] + 1.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) x[r][l] = xc[r][l];
+#pragma unroll
+                for (int l = 0; l < N; ++l)
+#pragma unroll
+                    for (int j = l; j < N; ++j) {
+                        double v = p[r][Sym<N>::at(l, j)];
+                        v = fma(-kk[r][l], gp[r][j], v);
+                        v = fma(-gp[r][l], kk[r][j], v);
+                        v = fma(c2 * kk[r][l], kk[r][j], v);
+                        p[r][Sym<N>::at(l, j)] = v;
+                    }
             }
         }
     }

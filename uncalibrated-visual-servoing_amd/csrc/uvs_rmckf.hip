@@ -353,8 +353,9 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
     if (!fp) return fail(UVS_ERR_ARG, "%s", "filter params are NULL");
     if (T <= 0) return fail(UVS_ERR_ARG, "%s", "T must be positive");
     if (fp->steps < 0 || fp->k_max <= 0) return fail(UVS_ERR_ARG, "%s", "steps must be >= 0 and k_max > 0");
-    if (fp->method != UVS_METHOD_KF && fp->method != UVS_METHOD_IMCCKF && fp->method != UVS_METHOD_GMCKF)
-        return fail(UVS_ERR_METHOD, "%s", "method must be KF, IMCCKF or GMCKF on the HIP path");
+    if (fp->method != UVS_METHOD_KF && fp->method != UVS_METHOD_MCKF && fp->method != UVS_METHOD_IMCCKF && fp->method != UVS_METHOD_GMCKF)
+        return fail(UVS_ERR_METHOD, "%s", "method must be KF, MCKF, IMCCKF or GMCKF");
+    if (fp->method == UVS_METHOD_MCKF && fp->fpi_epoch_max < 1) return fail(UVS_ERR_ARG, "%s", "MCKF needs fpi_epoch_max >= 1");
     const int L = fp->lanes_per_filter < 0 ? -fp->lanes_per_filter : (fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n));
     if (L == 0) return fail(UVS_ERR_SHAPE, "%s", "(m, n) is not instantiated in libuvs_rmckf");
     *lanes = L;

@@ -31,7 +31,7 @@ def loop_clock(t_s, t_max):
 
 
 def make_params(m, n, method='GMCKF', kernel_bw=10.0, annealing=False, t_s=0.05, t_max=15.0, gain=0.2, desired=None,
-                initial_guess=True, lanes=0, steps=None):
+                initial_guess=True, lanes=0, steps=None, fpi_threshold=0.1, fpi_epoch_max=1000):
     code = METHOD_CODES[method] if isinstance(method, str) else int(getattr(method, 'value', method))
     fp = FilterParams()
     fp.m, fp.n, fp.method, fp.annealing = m, n, code, int(bool(annealing))
@@ -39,6 +39,7 @@ def make_params(m, n, method='GMCKF', kernel_bw=10.0, annealing=False, t_s=0.05,
     fp.steps = len(loop_clock(t_s, t_max)) if steps is None else int(steps)
     fp.initial_guess, fp.lanes_per_filter = int(bool(initial_guess)), int(lanes)
     fp.kernel_bw, fp.anneal_span, fp.gain, fp.dt, fp.reg = float(kernel_bw), ANNEAL_SPAN, float(gain), float(t_s), REG
+    fp.fpi_threshold, fp.fpi_epoch_max = float(fpi_threshold), int(fpi_epoch_max)
     if m > _lib.UVS_MAX_M or n > _lib.UVS_MAX_N:
         raise ValueError('(m, n) exceeds UVS_MAX_M / UVS_MAX_N')
     if desired is not None:

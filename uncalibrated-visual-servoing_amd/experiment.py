@@ -41,7 +41,7 @@ def detect4Circles(image):
     raise NotImplementedError('no circle detector: bind experiment.detect4Circles to your perception front-end')
 
 
-_GPU_METHODS = (Method.KF, Method.IMCCKF, Method.GMCKF)
+_GPU_METHODS = (Method.KF, Method.MCKF, Method.IMCCKF, Method.GMCKF)
 
 
 class Experiment:
@@ -67,11 +67,20 @@ class Experiment:
     # ------------------------------------------------------------------------------------------------
     def _params(self, m, n, steps=None):
         return engine.make_params(m, n, self.method.name, getattr(self, 'kernel_bw', 1.0), getattr(self, 'annealing', False),
-                                  self.t_s, self.t_max, self.ibvs_gain, self.desired_f, self.initial_guess, self.lanes, steps)
+                                  self.t_s, self.t_max, self.ibvs_gain, self.desired_f, self.initial_guess, self.lanes, steps,
+                                  getattr(self, 'fpi_threshold', 0.1), getattr(self, 'fpi_epoch_max', 1000))
+
+    def _bandwidth_log(self, k):
+        """kernel_bw_log: the annealed bandwidth for MCKF, -1 for every other method (experiment.py:330)."""
+        if self.method != Method.MCKF:
+            return np.full(k, -1.0)
+        k_max = int(self.t_max / self.t_s)
+        steps = np.arange(k)
+        return (self.kernel_bw + 100 * (1 - steps / k_max)) if self.annealing else np.full(k, float(self.kernel_bw))
 
     def run(self) -> list:
         if self.method not in _GPU_METHODS:
-            raise NotImplementedError(f'{self.method.name} is not on the HIP path (KF, IMCCKF, GMCKF are)')
+            raise NotImplementedError(f'{self.method.name} is not an estimator of the HIP path (KF, MCKF, IMCCKF, GMCKF are)')
         if isinstance(self.robot, SyntheticRobot):
             return self._run_on_device_plant()
         return self._run_with_external_robot()
@@ -109,7 +118,7 @@ class Experiment:
             self.logger.error('Experiment failed')
         else:
             self.logger.info('Experiment success')
-        bw_log = np.full(k, -1.0)                                    # -1 unless MCKF (experiment.py:330)
+        bw_log = self._bandwidth_log(k)
         return (status, t_log[:k], err, q_log, f_log, np.tile(np.asarray(self.desired_f, float), (k, 1)), cam, noise_log[:k], bw_log)
 
     # ---- route 2: external robot, estimator step on the GPU ------------------------------------------
@@ -160,7 +169,7 @@ class Experiment:
             q_now = robot.getJointsPos()
             new_q = q_now + dq * self.t_s
             logs['q'][k], logs['cam'][k], logs['f'][k], logs['des'][k] = q_now, robot.computePose(), f, self.desired_f
-            logs['err'][k], logs['noise'][k], logs['t'][k], logs['bw'][k] = err_t[0].cpu().numpy(), noise, t, -1
+            logs['err'][k], logs['noise'][k], logs['t'][k] = err_t[0].cpu().numpy(), noise, t
             k += 1
             robot.setJointsPos(new_q)
             robot.step()
@@ -168,7 +177,7 @@ class Experiment:
         if status == ExperimentStatus.SUCCESS:
             self.logger.info('Experiment success')
         return (status, logs['t'][:k], logs['err'][:k], logs['q'][:k], logs['f'][:k], logs['des'][:k], logs['cam'][:k],
-                logs['noise'][:k], logs['bw'][:k])
+                logs['noise'][:k], self._bandwidth_log(k))
 
     @staticmethod
     def _analytic_guess(robot, f, resolution, m, n):
