@@ -348,7 +348,6 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
     double diag[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        constexpr int dummy = 0; (void)dummy;
         const int owner = c / R, prow = c % R;                    // lane / local row holding global row c
         double sig = 0.0;
 #pragma unroll

@@ -1,16 +1,21 @@
-// Tuned closed-loop kernel: L = 1 or 2 lanes per filter, the headline path (BASELINE config 2).
+// Tuned closed-loop kernel: 1, 2 or 4 lanes per filter -- the headline path (BASELINE config 2 runs it with L = 2).
 //
 // Sizing.  65 536 trials x (8 blocks x 21 doubles of P) is 88 MB -- 69 % of the chip's whole VGPR+AGPR file
-// (1024 SIMDs x 512 regs x 64 lanes x 4 B) and twice its LDS -- so P lives in registers, at most one wavefront fits per
-// SIMD and nothing hides latency: any scratch spill is a full memory round trip on the critical path (measured: 250 scratch
-// loads per step cost 7x the arithmetic).  Only 256 of the 512 registers are VALU-addressable.  Hence:
-//   * L lanes share a filter, lane s owning rows s, s+L, s+2L, ... (interleaved, so both lanes of a pair run the same
-//     static Householder code); per lane P is (m/L) x 21 doubles in VGPRs;
-//   * X ((m/L)*n doubles per lane) and the ISE/IAE/ITAE accumulators live in LDS as [component][lane] (conflict free);
-//   * the pair exchanges partial sums / pivots with DPP quad_perm moves (no LDS, no ds_bpermute);
-//   * every global access is  s[wavefront base] + v[lane offset]: stream bases advance in SGPRs;
-//   * divisions / roots / sincos come from rmckf_math.hpp.
-// With the trial-fastest layout ([step][component][trial]) each wavefront store covers 512 / L contiguous bytes per row set.
+// (1024 SIMDs x 512 regs x 64 lanes x 4 B) and twice its LDS -- so P lives in registers, one (L <= 2) or two (L = 4)
+// wavefronts fit per SIMD and nothing hides latency: a scratch spill is a full memory round trip on the critical path
+// (measured: 250 scratch loads per step cost 7x the arithmetic).  Only 256 of the 512 registers are VALU-addressable; the
+// AGPR half and LDS are parking space at ~20 cycles per double and round trip.  With one wavefront per SIMD every
+// instruction of any kind costs a ~4.5-cycle issue slot, so the design minimises instruction count and branches:
+//   * L lanes share a filter, lane s owning rows s, s+L, s+2L, ... (interleaved, so all lanes run the same static
+//     Householder code and the (u, v) rows of a point fall on even / odd lanes);
+//   * L = 2: half of the lane's covariance blocks stay in VGPRs, the other half, X and the ISE/IAE/ITAE accumulators live in
+//     LDS as [component][lane] (conflict free); L = 4: everything but the accumulators is in VGPRs;
+//   * group exchanges (partial sums, pivots, kinematic partial products) are DPP quad_perm moves -- no LDS, no ds_bpermute;
+//   * the kinematic chain is split over the lanes (3 + 3 links for L = 2, 2 + 2 + 2 for L = 4), each lane tracks only its joints;
+//   * plant constants are broadcast from LDS instead of occupying ~90 SGPRs that would spill to VGPR lanes;
+//   * per-lane stream cursors advance by uniform strides; the step body is straight-line code with unconditional stores;
+//   * divisions / roots / sincos come from rmckf_math.hpp (v_rcp/v_rsq + Newton steps, bounded-argument sincos).
+// With the trial-fastest layout ([step][component][trial]) each wavefront store covers 512 / L contiguous bytes per owned row.
 #pragma once
 #include "rmckf_device.hpp"
 #include "rmckf_math.hpp"
@@ -101,7 +106,6 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     double rdiag[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        constexpr int dummy = 0; (void)dummy;
         const int m = c / L, owner = c % L;
         const bool is_piv = (L == 1) || (sub == owner);
         const bool is_below = (L > 1) && (sub > owner);
