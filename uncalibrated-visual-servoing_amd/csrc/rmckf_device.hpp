@@ -14,31 +14,76 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "uvs_rmckf.h"
+#include "rmckf_math.hpp"
 
 namespace uvs {
 
+#ifndef UVS_DEV
 #define UVS_DEV __device__ __forceinline__
+#endif
 
 // ---------------------------------------------------------------- cross-lane helpers
-// Sum over the L consecutive lanes of a group; every lane receives the bit-identical total
-// (xor butterfly: both partners add the same two operands).
+// The L lanes of a filter are consecutive and L divides 64.  Up to 16 lanes form (part of) one DPP row, so reductions and
+// broadcasts are DPP moves (VALU, no LDS): butterfly stages quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
+// row_mirror; beyond a row the last stages fall back to ds_bpermute (__shfl_xor).  Verified on gfx950 (tools/ubench/dpp_test).
+template <int CTRL>
+UVS_DEV int dpp_mov32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+UVS_DEV double dpp_mov64(double v) {
+    return __hiloint2double(dpp_mov32<CTRL>(__double2hiint(v)), dpp_mov32<CTRL>(__double2loint(v)));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppNewBcast = 0x150;
+
+// Sum over the L lanes of a group; every lane receives the bit-identical total (both partners of a stage add the same pair).
 template <int L>
 UVS_DEV double group_sum(double v) {
-#pragma unroll
-    for (int off = 1; off < L; off <<= 1) v += __shfl_xor(v, off, 64);
+    if constexpr (L >= 2) v += dpp_mov64<kDppXor1>(v);
+    if constexpr (L >= 4) v += dpp_mov64<kDppXor2>(v);
+    if constexpr (L >= 8) v += dpp_mov64<kDppHalfMirror>(v);
+    if constexpr (L >= 16) v += dpp_mov64<kDppMirror>(v);
+    if constexpr (L >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 template <int L>
 UVS_DEV int group_or(int v) {
-#pragma unroll
-    for (int off = 1; off < L; off <<= 1) v |= __shfl_xor(v, off, 64);
+    if constexpr (L >= 2) v |= dpp_mov32<kDppXor1>(v);
+    if constexpr (L >= 4) v |= dpp_mov32<kDppXor2>(v);
+    if constexpr (L >= 8) v |= dpp_mov32<kDppHalfMirror>(v);
+    if constexpr (L >= 16) v |= dpp_mov32<kDppMirror>(v);
+    if constexpr (L >= 32) v |= __shfl_xor(v, 16, 64);
+    if constexpr (L >= 64) v |= __shfl_xor(v, 32, 64);
     return v;
 }
-// Value held by the lane whose group-relative index is `owner` (others pass anything).
+// Broadcast of group lane OWNER to the whole group (L <= 16): quad_perm inside a quad, row_newbcast inside a row
+// (with bank masks when two groups of 8 share the row).
+template <int L, int OWNER>
+UVS_DEV int group_bcast32(int v) {
+    if constexpr (L == 2) return dpp_mov32<OWNER | (OWNER << 2) | ((2 + OWNER) << 4) | ((2 + OWNER) << 6)>(v);
+    else if constexpr (L == 4) return dpp_mov32<OWNER * 0x55>(v);
+    else if constexpr (L == 8) {
+        int r = __builtin_amdgcn_update_dpp(0, v, kDppNewBcast + OWNER, 0xf, 0x3, false);
+        return __builtin_amdgcn_update_dpp(r, v, kDppNewBcast + 8 + OWNER, 0xf, 0xC, false);
+    } else return dpp_mov32<kDppNewBcast + OWNER>(v);
+}
+template <int L, int OWNER>
+UVS_DEV double group_bcast(double v) {
+    return __hiloint2double(group_bcast32<L, OWNER>(__double2hiint(v)), group_bcast32<L, OWNER>(__double2loint(v)));
+}
+// Value held by the lane whose group-relative index is `owner` (a compile-time constant after unrolling; others pass anything).
 template <int L>
 UVS_DEV double group_pick(double v, int sub, int owner) {
     if constexpr (L == 1) return v;
-    return group_sum<L>(sub == owner ? v : 0.0);
+    else if constexpr (L > 16) return group_sum<L>(sub == owner ? v : 0.0);
+    else {
+        switch (owner & (L - 1)) {
+#define UVS_CASE(O) case O: return group_bcast<L, (O < L ? O : 0)>(v);
+            UVS_CASE(0) UVS_CASE(1) UVS_CASE(2) UVS_CASE(3) UVS_CASE(4) UVS_CASE(5) UVS_CASE(6) UVS_CASE(7)
+            UVS_CASE(8) UVS_CASE(9) UVS_CASE(10) UVS_CASE(11) UVS_CASE(12) UVS_CASE(13) UVS_CASE(14) UVS_CASE(15)
+#undef UVS_CASE
+            default: return v;
+        }
+    }
 }
 
 UVS_DEV bool finite64(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000LL) != 0x7ff0000000000000LL; }
@@ -118,10 +163,16 @@ struct Rows {
     //   P_i += I; nu_i = z_i - x_i.h; weight; g = P_i h; a = h.g; gamma; x_i += gamma g nu_i;
     //   Joseph with R = 1 collapses to the symmetric rank-1 downdate P_i -= gamma (2 - gamma (a + 1)) g g^T.
     // kap[] receives the correntropy weights kappa_i that the control law re-uses (experiment.py:308).
-    UVS_DEV void update(const uvs_filter_params &fp, const double (&z)[R], const double (&h)[N], double sigma, double (&kap)[R]) {
-        if (fp.method == UVS_METHOD_MCKF) {
-            update_mckf(fp, z, h, sigma, kap);
-            return;
+    // METHOD_T != 0 fixes the estimator at compile time (the other paths are not even compiled into that kernel, which keeps
+    // its register allocation at what the estimator needs); METHOD_T == 0 reads fp.method at run time.
+    template <int METHOD_T = 0>
+    UVS_DEV void update(const uvs_filter_params &fp_in, const double (&z)[R], const double (&h)[N], double sigma, double (&kap)[R]) {
+        struct { int method; double reg, fpi_threshold; int fpi_epoch_max; } fp{METHOD_T ? METHOD_T : fp_in.method, fp_in.reg, fp_in.fpi_threshold, fp_in.fpi_epoch_max};
+        if constexpr (METHOD_T == 0 || METHOD_T == UVS_METHOD_MCKF) {
+            if (fp.method == UVS_METHOD_MCKF) {
+                update_mckf(fp_in, z, h, sigma, kap);
+                return;
+            }
         }
         double nu[R];
 #pragma unroll
@@ -156,14 +207,14 @@ struct Rows {
             double gamma;
             if (fp.method == UVS_METHOD_GMCKF) {                                 // experiment.py:276-286
                 kap[r] = gaussian_kernel(nu[r], sigma);
-                const double r_hat = 1.0 / (kap[r] + fp.reg);
-                gamma = 1.0 / (a + r_hat);
+                const double dd = kap[r] + fp.reg;                               // 1 / (a + 1/dd) = dd / (a dd + 1)
+                gamma = dd * fast_rcp(fma(a, dd, 1.0));
             } else if (fp.method == UVS_METHOD_IMCCKF) {                         // experiment.py:262-264
                 kap[r] = 1.0;
-                gamma = c_shared / (c_shared * a + 1.0);
+                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
             } else {                                                             // KF, experiment.py:192
                 kap[r] = 1.0;
-                gamma = 1.0 / (a + 1.0);
+                gamma = fast_rcp(a + 1.0);
             }
             const double step = gamma * nu[r];
             const double beta = gamma * (2.0 - gamma * (a + 1.0));
@@ -357,11 +408,13 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
         }
         sig = group_sum<L>(sig);
         const double piv = group_pick<L>(a[prow][c], sub, owner);
-        const double nrm = sqrt(fma(piv, piv, sig));
+        const double n2 = fma(piv, piv, sig);
+        double nrm, rn;
+        fast_sqrt_rsqrt_1(n2, nrm, rn);                           // |R_cc| and its reciprocal
         const double alpha = (piv >= 0.0) ? -nrm : nrm;
         const double vp = piv - alpha;                            // pivot entry of the Householder vector
-        const double denom = nrm * (nrm + fabs(piv));             // v.v / 2
-        const double tau = (denom > 0.0) ? 1.0 / denom : 0.0;
+        const double denom = n2;                                  // zero column <=> nothing to eliminate
+        const double tau = (denom > 0.0) ? rn * fast_rcp_1(fabs(vp)) : 0.0;   // 2 / (v.v) = 1 / (nrm (nrm + |piv|))
         const bool mine = (L == 1) ? true : (sub == owner);
 #pragma unroll
         for (int j = c + 1; j <= N; ++j) {
@@ -380,7 +433,7 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
             }
             a[prow][j] = mine ? fma(-d, vp, a[prow][j]) : a[prow][j];
         }
-        diag[c] = (denom > 0.0) ? alpha : piv;                    // zero column below the pivot: R_cc = piv
+        diag[c] = (denom > 0.0) ? ((piv >= 0.0) ? -rn : rn) : 0.0;  // 1 / R_cc (0 marks a zero column)
     }
 #pragma unroll
     for (int c = N - 1; c >= 0; --c) {
@@ -389,7 +442,7 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
 #pragma unroll
         for (int j = c + 1; j < N; ++j) rhs = fma(-a[prow][j], sol[j], rhs);
         rhs = group_pick<L>(rhs, sub, owner);
-        sol[c] = (diag[c] != 0.0) ? rhs / diag[c] : 0.0;
+        sol[c] = rhs * diag[c];
     }
 }
 

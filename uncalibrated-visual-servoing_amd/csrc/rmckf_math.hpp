@@ -10,7 +10,9 @@
 
 namespace uvs {
 
+#ifndef UVS_DEV
 #define UVS_DEV __device__ __forceinline__
+#endif
 
 // 1/d for normal d: v_rcp_f64 seeds ~2^-23 relative error; two Newton steps reach ~2^-52.
 UVS_DEV double fast_rcp(double d) {

@@ -36,7 +36,7 @@ UVS_DEV void store_final(const Rows<M, N, L> &st, const View &xf, const View &pf
 }
 
 // ------------------------------------------------------------------------------------------------ closed loop
-template <int M, int N, int L>
+template <int M, int N, int L, int METHOD_T>
 __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
     constexpr int R = M / L;
     const long long gl = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];                                             // experiment.py:302
         }
-        st.update(fp, z, dq, bandwidth(fp, k), kap);                            // h = previous command; zero on k = 0
+        st.template update<METHOD_T>(fp, z, dq, bandwidth(fp, k), kap);                            // h = previous command; zero on k = 0
         if (alive && st.any_nonfinite()) {                                      // pinv raises -> FAIL, break (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ replay
-template <int M, int N, int L>
+template <int M, int N, int L, int METHOD_T>
 __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
     constexpr int R = M / L;
     const long long gl = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];
         }
-        st.update(fp, z, h, bandwidth(fp, k), kap);
+        st.template update<METHOD_T>(fp, z, h, bandwidth(fp, k), kap);
         if (alive && st.any_nonfinite()) {
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ single step
-template <int M, int N, int L>
+template <int M, int N, int L, int METHOD_T>
 __global__ __launch_bounds__(64) void step_kernel(const StepArgs A) {
     constexpr int R = M / L;
     const long long gl = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs A) {
 #pragma unroll
             for (int j = l; j < N; ++j) st.p[r][Sym<N>::at(l, j)] = A.P[((trial * M + row) * N + l) * N + j];
     }
-    st.update(fp, z, h, bandwidth(fp, A.k), kap);
+    st.template update<METHOD_T>(fp, z, h, bandwidth(fp, A.k), kap);
     const int bad = st.any_nonfinite();
     control_law<M, N, L>(st, kap, err, fp.gain, sub, cmd);
     if (!valid) return;
@@ -433,7 +433,8 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
 #undef XT
 #define X(M, N, LL) \
     if (!launched && fp->m == M && fp->n == N && L == LL) { \
-        hipLaunchKernelGGL((uvs::closed_loop_kernel<M, N, LL>), grid_for(T, LL), dim3(64), 0, s, A); \
+        if (fp->method == UVS_METHOD_GMCKF) hipLaunchKernelGGL((uvs::closed_loop_kernel<M, N, LL, UVS_METHOD_GMCKF>), grid_for(T, LL), dim3(64), 0, s, A); \
+        else hipLaunchKernelGGL((uvs::closed_loop_kernel<M, N, LL, 0>), grid_for(T, LL), dim3(64), 0, s, A); \
         launched = true; \
     }
     UVS_SHAPES(X)
@@ -459,7 +460,8 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     bool launched = false;
 #define X(M, N, LL) \
     if (!launched && fp->m == M && fp->n == N && L == LL) { \
-        hipLaunchKernelGGL((uvs::replay_kernel<M, N, LL>), grid_for(T, LL), dim3(64), 0, s, A); \
+        if (fp->method == UVS_METHOD_GMCKF) hipLaunchKernelGGL((uvs::replay_kernel<M, N, LL, UVS_METHOD_GMCKF>), grid_for(T, LL), dim3(64), 0, s, A); \
+        else hipLaunchKernelGGL((uvs::replay_kernel<M, N, LL, 0>), grid_for(T, LL), dim3(64), 0, s, A); \
         launched = true; \
     }
     UVS_SHAPES(X)
@@ -480,7 +482,7 @@ int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double
     bool launched = false;
 #define X(M, N, LL) \
     if (!launched && fp->m == M && fp->n == N && L == LL) { \
-        hipLaunchKernelGGL((uvs::step_kernel<M, N, LL>), grid_for(T, LL), dim3(64), 0, s, A); \
+        hipLaunchKernelGGL((uvs::step_kernel<M, N, LL, 0>), grid_for(T, LL), dim3(64), 0, s, A); \
         launched = true; \
     }
     UVS_SHAPES(X)
