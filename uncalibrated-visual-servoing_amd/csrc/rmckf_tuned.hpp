@@ -435,6 +435,19 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
         UVS_STAMP(0);                                            // noise-load issue + plant
         const double sigma = bandwidth(fp, k);
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
+        double c_shared = 1.0;
+        if constexpr (METHOD == UVS_METHOD_IMCCKF) {             // one weight for the whole filter: G(||Z - H X||) (experiment.py:258-261)
+            double ss = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane], dq[j], pred);
+                const double nu = (z[r] + nz[r] - f_prev[r]) - pred;
+                ss = fma(nu, nu, ss);
+            }
+            c_shared = exp(pair_sum<L>(ss) * neg_half_inv_s2);   // sqrt(.)**2 of the reference folded: G(n) = exp(-n^2 / (2 sigma^2))
+        }
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
         double *pxr = px;
@@ -478,6 +491,9 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #endif
                 const double d = kap[r] + fp.reg;                // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
                 gamma = d * fast_rcp(fma(a, d, 1.0));
+            } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {  // K = c P H^T (c H P H^T + R)^-1 (experiment.py:262-264)
+                kap[r] = 1.0;
+                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
             } else {                                             // KF (experiment.py:192)
                 kap[r] = 1.0;
                 gamma = fast_rcp(a + 1.0);

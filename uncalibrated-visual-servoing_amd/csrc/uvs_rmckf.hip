@@ -372,9 +372,11 @@ void launch_tuned2(bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
     else hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, METHOD, PLANT, PV, false>), g, dim3(64), 0, s, A);
 }
 template <int M, int N, int LL>
-void launch_tuned(bool gmckf, bool linear, bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
-    if (gmckf && !linear) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
-    else if (gmckf) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>(xo, g, s, A);
+void launch_tuned(int method, bool linear, bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
+    if (method == UVS_METHOD_GMCKF && !linear) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
+    else if (method == UVS_METHOD_GMCKF) launch_tuned2<M, N, LL, UVS_METHOD_GMCKF, UVS_PLANT_LINEAR>(xo, g, s, A);
+    else if (method == UVS_METHOD_IMCCKF && !linear) launch_tuned2<M, N, LL, UVS_METHOD_IMCCKF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
+    else if (method == UVS_METHOD_IMCCKF) launch_tuned2<M, N, LL, UVS_METHOD_IMCCKF, UVS_PLANT_LINEAR>(xo, g, s, A);
     else if (!linear) launch_tuned2<M, N, LL, UVS_METHOD_KF, UVS_PLANT_DH_PINHOLE>(xo, g, s, A);
     else launch_tuned2<M, N, LL, UVS_METHOD_KF, UVS_PLANT_LINEAR>(xo, g, s, A);
 }
@@ -423,10 +425,10 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     bool launched = false;
     // lanes_per_filter 1 / 2 / 4 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic
     // template with |value| lanes (kept as an in-library cross-check of the tuned code).
-    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF) && fp->lanes_per_filter >= 0;
+    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF) && fp->lanes_per_filter >= 0;
 #define XT(M, N, LL) \
     if (!launched && tuned_ok && L == LL && fp->m == M && fp->n == N) { \
-        launch_tuned<M, N, LL>(fp->method == UVS_METHOD_GMCKF, plant->kind == UVS_PLANT_LINEAR, x_out.base != nullptr, grid_for(T, LL), s, A); \
+        launch_tuned<M, N, LL>(fp->method, plant->kind == UVS_PLANT_LINEAR, x_out.base != nullptr, grid_for(T, LL), s, A); \
         launched = true; \
     }
     UVS_TUNED_SHAPES(XT)
