@@ -46,3 +46,8 @@ def test_sincos_bounded_and_fallback():
 def test_exp_on_kernel_range():
     x = -np.exp(np.random.default_rng(2).uniform(np.log(1e-12), np.log(700), 200000))
     assert _ulps(_eval(5, x), np.exp(x)).max() <= 2.0
+    assert _ulps(_eval(6, x), np.exp(x)).max() <= 2.0                       # exp_nonpos, the form the tuned kernel uses
+    edge = np.array([0.0, -0.0, -1e-300, -745.0, -746.0, -1000.0, -1e300, -np.inf])
+    got = _eval(6, edge)
+    assert got[0] == 1.0 and got[1] == 1.0 and got[2] == 1.0 and np.all(got[4:] == 0.0) and abs(got[3] / np.exp(-745.0) - 1) < 1e-3
+    assert np.isnan(_eval(6, np.array([np.nan]))[0])

@@ -56,6 +56,30 @@ UVS_DEV void fast_sqrt_rsqrt_1(double a, double &s, double &rs) {
     rs = h + h;
 }
 
+// exp(x) for x <= 0 (the correntropy weight exp(-e^2 / (2 sigma^2))): Cody-Waite reduction by ln 2, degree-13 Taylor polynomial on
+// |r| <= ln2/2 (truncation 4e-18), v_ldexp for the scale (which also produces the denormal / zero tail).  NaN stays NaN; -inf -> 0.
+UVS_DEV double exp_nonpos(double x) {
+    x = (x < -800.0) ? -800.0 : x;                         // exp underflows to 0 below; keeps the integer conversion in range; NaN passes
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                     // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                  // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                  // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                 // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                   // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                  // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);                  // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                  // 1/5!
+    p = fma(p, r, 4.166666666666666e-02);                  // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
 // sin and cos for |x| <= ~1e5 rad: Cody-Waite reduction by pi/2 in three 33-bit pieces (exact products for
 // |k| < 2^20), then the classic minimax kernels on [-pi/4, pi/4] (fdlibm-style coefficients).  < 1 ulp.
 UVS_DEV void sincos_bounded(double x, double &s, double &c) {

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                 const double nu = (z[r] + nz[r] - f_prev[r]) - pred;
                 ss = fma(nu, nu, ss);
             }
-            c_shared = exp(pair_sum<L>(ss) * neg_half_inv_s2);   // sqrt(.)**2 of the reference folded: G(n) = exp(-n^2 / (2 sigma^2))
+            c_shared = exp_nonpos(pair_sum<L>(ss) * neg_half_inv_s2);   // sqrt(.)**2 of the reference folded: G(n) = exp(-n^2 / (2 sigma^2))
         }
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #ifdef UVS_ABLATE_EXP
                 kap[r] = fast_rcp(fma(nu * nu, -neg_half_inv_s2, 1.0));
 #else
-                kap[r] = exp((nu * nu) * neg_half_inv_s2);       // utils.py:171-172
+                kap[r] = exp_nonpos((nu * nu) * neg_half_inv_s2);   // utils.py:171-172
 #endif
                 const double d = kap[r] + fp.reg;                // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
                 gamma = d * fast_rcp(fma(a, d, 1.0));

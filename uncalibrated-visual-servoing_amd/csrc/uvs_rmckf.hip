@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void debug_math_kernel(int which, long long n,
         case 2: fast_sqrt_rsqrt(v, s, r); y[i] = r; break;
         case 3: sincos_any(v, s, c); y[i] = s; break;
         case 4: sincos_any(v, s, c); y[i] = c; break;
+        case 6: y[i] = exp_nonpos(v); break;
         default: y[i] = exp(v); break;
     }
 }
