@@ -89,7 +89,7 @@ def _cpu_trial(args):
     return out['k_done'], time.perf_counter() - t0
 
 
-def cpu_baseline(q_starts, budget_trials_per_core=24):
+def cpu_baseline(q_starts, budget_trials_per_core=16):
     """Dense numpy restatement of the reference loop (oracle/rmckf_dense.py, op-for-op experiment.py:125-343) on all host cores."""
     os.environ['OPENBLAS_NUM_THREADS'] = '1'
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)

@@ -17,6 +17,12 @@ NOISE_KIND = dict(WHITE_NOISE=1, GAUSSIAN_MIXTURE=2, GAUSSIAN_BIMODAL=3, ALPHA_S
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The HIP library is a build artefact (git-ignored).  If this checkout has not been built yet, build it now: hipcc
+    # cross-compiles gfx950 without a GPU.  On the GPU box the prebuilt .so travels with the snapshot and nothing happens.
+    lib = os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'libuvs_rmckf.so')
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'csrc')], check=True)
 
 
 def golden_names(prefix):

@@ -222,6 +222,30 @@ def test_non_finite_state_fails_the_trial_only(uvs):
     assert np.array_equal(err[:bad_step, :, 2], err[:bad_step, :, 0])      # rows >= k_done are unspecified (the reference trims them)
 
 
+def test_empty_and_degenerate_batches(uvs):
+    """T = 0 is an argument error (nothing to launch); K = 0 runs no step: SUCCESS, zero rows, zero statistics; a single trial
+    and a ragged batch (not a multiple of the 32 trials of a wavefront) behave like slices of a bigger batch."""
+    import ctypes as C
+    g = load_golden('closed_gmckf_a1p5')
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    fp = _fp(uvs, g, steps=0)
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(np.tile(g['q_start'], (5, 1))), None, want=('err',))
+    assert out['k_done'].tolist() == [0] * 5 and out['status'].tolist() == [0] * 5 and float(out['stats'].abs().max()) == 0.0
+    V = uvs._lib.NULL_VIEW
+    rc = uvs.lib().uvs_rmckf_closed_loop_f64(C.byref(fp), C.byref(plant.to_struct()), 0, V, V, V, V, V, V, V, V, None, None, None, V, V, None)
+    assert rc == -1
+    K = 30
+    fp = _fp(uvs, g, steps=K)
+    q0 = np.tile(g['q_start'], (37, 1))
+    q0[:, 1] -= np.linspace(0, 0.3, 37)
+    noise = np.random.default_rng(4).standard_t(3, size=(K, 8, 37))
+    big = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise), want=('err', 'x'))
+    one = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0[36:37]), _cuda(noise[:, :, 36:37]), want=('err', 'x'))
+    assert np.array_equal(big['err'].cpu().numpy()[:, :, 36], one['err'].cpu().numpy()[:, :, 0])
+    assert np.array_equal(big['x'].cpu().numpy()[:, :, 36], one['x'].cpu().numpy()[:, :, 0])
+    assert np.array_equal(big['stats'].cpu().numpy()[36], one['stats'].cpu().numpy()[0])
+
+
 # ---------------------------------------------------------------------------------------------- statistics kernel
 def test_stats_kernel_matches_matlab_definition(uvs):
     from oracle.rmckf_dense import trial_stats
