@@ -119,6 +119,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
+    ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
     ap.add_argument('--layout', default='kct', choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams')
     args = ap.parse_args()
@@ -215,8 +216,9 @@ def main():
 
     def launch():
         rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV if x0 is None else flat(x0), engine.stream_view(bufs['x'], args.layout),
-            engine.stream_view(bufs['err'], args.layout), engine.stream_view(bufs['q'], args.layout), NV, NV, stats.data_ptr(), status.data_ptr(),
+            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV if x0 is None else flat(x0),
+            NV if args.stats_only else engine.stream_view(bufs['x'], args.layout),
+            NV if args.stats_only else engine.stream_view(bufs['err'], args.layout), NV if args.stats_only else engine.stream_view(bufs['q'], args.layout), NV, NV, stats.data_ptr(), status.data_ptr(),
             k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         uvs_amd._lib.check(rc)
 
@@ -267,11 +269,13 @@ def main():
 
     if rank == 0:
         b_alg = 8 * (2 * M + N + M * N)                           # 560 B / update at (8,6): noise in, err + X + q out
+        if args.stats_only:
+            b_alg = 8 * M                                         # only the noise stream is read; statistics are 24 B per trial
         avg_ms = float(np.mean(kernel_ms))
         achieved = updates_per_launch * b_alg / (avg_ms * 1e-3) / 1e9
         traffic = None
         tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
+        if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2) and not args.stats_only:
             traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')     # rocprofv3 PMC, measured on exactly this launch shape
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
@@ -280,7 +284,7 @@ def main():
             'config': {'workload': {2: 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, ',
                                     3: f'BASELINE config 3: 4-feature UR10 closed loop, GMCKF(RMCKF) annealed sigma, Gaussian mixture rho=0.1 mean=50 hold={bool(args.hold)}, ',
                                     5: 'BASELINE config 5: synthetic 16-feature / 7-DoF (m=32, n=7) linear plant, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5, '}[args.config] +
-                                   f'{T} trials/GPU x {K} updates, X+err+q logged per step', 'trials_per_gpu': T, 'updates_per_trial': K,
+                                   f'{T} trials/GPU x {K} updates, ' + ('statistics only (no per-step streams)' if args.stats_only else 'X+err+q logged per step'), 'trials_per_gpu': T, 'updates_per_trial': K,
                        'lanes_per_filter': args.lanes or engine.supported_lanes(M, N)[0], 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
