@@ -5,7 +5,6 @@ rank r owns the contiguous global trials [lo, hi) and runs them exactly as a sin
 jitter draws), which makes a G-GPU sweep bit-identical to the 1-GPU sweep.  The only exchange is one end-of-run
 all-gather of the per-trial [ISE, IAE, ITAE, status] rows (32 B per trial) over xGMI.
 """
-import numpy as np
 
 
 def shard_range(total, rank, world):
