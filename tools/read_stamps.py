@@ -25,9 +25,14 @@ torch.cuda.synchronize()
 stats = out['stats'].cpu().numpy().ravel()
 tpw = 64 // lanes
 waves = T // tpw
-st = np.stack([stats[3 * w * tpw: 3 * w * tpw + 6] for w in range(waves)])
-names = ['noise-issue + plant', 'row updates', 'control law (QR)', 'logs + stats', '(unused)', 'loop edge']
+st = np.stack([stats[3 * w * tpw: 3 * w * tpw + 8] for w in range(waves)])
+names = ['noise-issue + plant', 'row updates', 'control law (QR)', 'logs + stats', '(100 MHz wall ticks)', 'loop edge', 'vmcnt(0) wait before the rows', '(unused)']
+rt = st[:, 4].copy()
+st[:, 4] = 0
 tot = st.sum(axis=1)
 print(f'waves {waves}, cycles per wave: mean {tot.mean():.0f}  min {tot.min():.0f}  max {tot.max():.0f};  per step {tot.mean() / K:.0f}')
+print(f'shader clock while the kernel runs: {tot.mean() / (rt.mean() / 100e6) / 1e9:.3f} GHz  (loop wall time {rt.mean() / 100e6 * 1e3:.3f} ms per wavefront)')
 for i, n in enumerate(names):
+    if i == 4:
+        continue
     print(f'  {n:24s} {st[:, i].mean() / K:9.0f} cycles/step  {100 * st[:, i].mean() / tot.mean():5.1f}%')

@@ -22,6 +22,13 @@
 
 namespace uvs {
 
+// Diagnostic build -DUVS_STORES_INPLACE: every step overwrites the rows of step 0/1 (same instructions, traffic stays in L2).
+#ifdef UVS_STORES_INPLACE
+#define UVS_SK(sk) ((k & 1) ? -(sk) : (sk))
+#else
+#define UVS_SK(sk) (sk)
+#endif
+
 // Diagnostic build -DUVS_STAMPS: per-phase cycle sums (s_memtime) of every wavefront, written over the first words of that
 // wavefront's slice of `stats` (which is therefore garbage in this build).  Never used in the shipped library.
 #ifdef UVS_STAMPS
@@ -294,8 +301,10 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true;
 #ifdef UVS_STAMPS
-    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    unsigned long long rt_first;                                 // constant 100 MHz counter: slot 4 = wall ticks of the loop -> shader clock
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
 #endif
 
     for (int k = 0; k < K; ++k) {
@@ -433,6 +442,10 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             }
         }
         UVS_STAMP(0);                                            // noise-load issue + plant
+#ifdef UVS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slot 6: how long the oldest outstanding memory operation still takes
+        UVS_STAMP(6);
+#endif
         const double sigma = bandwidth(fp, k);
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
         double c_shared = 1.0;
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                 else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
             }
         }
-        if constexpr (XOUT) px += A.x_out.sk;
+        if constexpr (XOUT) px += UVS_SK(A.x_out.sk);
         // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
         asm volatile("" ::: "memory");
         UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             double *pc = pe;
 #pragma unroll
             for (int r = 0; r < R; ++r) { *pc = err[r]; pc += L * A.err_out.sc; }
-            pe += A.err_out.sk;
+            pe += UVS_SK(A.err_out.sk);
         }
         if (on_f) {
             double *pc = pf;
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             double *pc = pq;
 #pragma unroll
             for (int u = 0; u < JG; ++u) { *pc = q[u]; pc += A.q_out.sc; }
-            pq += A.q_out.sk;
+            pq += UVS_SK(A.q_out.sk);
         }
         if (on_dq) {
             double *pc = pd;
@@ -619,8 +632,13 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
         t += fp.dt;
     }
 #ifdef UVS_STAMPS
+    {
+        unsigned long long rt_last;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_last)::"memory");
+        stamp_sum[4] = rt_last - rt_first;
+    }
     if (lane == 0 && A.stats) {
-        for (int c = 0; c < 6; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
+        for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
     }
     return;
 #endif

@@ -335,6 +335,10 @@ int check_launch(const char *what) {
 }
 
 // (m, n, lanes-per-filter) instantiations; the first listed L of a shape is its default.
+#ifdef UVS_QUICK                      // experiment builds (make quick): the headline shape only, compiles in seconds
+#define UVS_SHAPES(X) X(8, 6, 2)
+#define UVS_TUNED_SHAPES(X) X(8, 6, 2)
+#else
 #define UVS_SHAPES(X) \
     X(8, 6, 2) X(8, 6, 1) X(8, 6, 4) X(8, 6, 8) \
     X(2, 6, 1) \
@@ -342,6 +346,7 @@ int check_launch(const char *what) {
     X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)
 
 #define UVS_TUNED_SHAPES(X) X(8, 6, 1) X(8, 6, 2) X(8, 6, 4) X(6, 6, 2)
+#endif
 
 int default_lanes(int m, int n) {
 #define X(M, N, L) if (m == M && n == N) return L;
