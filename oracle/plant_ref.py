@@ -172,3 +172,26 @@ class PinholeUR10:
 
     def features(self):
         return project(self.fkine(True), self.discs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic camera frames for the circle-detector fixtures: filled discs on a grey background, RGB uint8, row 0 at the
+# bottom like the simulator's vision sensor (the detectors flip the frame first, utils.py:13).
+DISC_COLOURS = {'red': (255, 0, 0), 'green': (0, 255, 0), 'blue': (0, 0, 255), 'pink': (255, 0, 255)}
+
+
+def render_discs(centres, radii, size=256, background=96, soften=False):
+    """centres: {colour: (u, v)} in pixels of the *flipped* frame (u right, v down); returns (size, size, 3) uint8.
+    soften=True adds an anti-aliased rim (values 97..254) that the 250 threshold must reject."""
+    vv, uu = np.mgrid[0:size, 0:size].astype(float)
+    img = np.full((size, size, 3), background, np.uint8)
+    for colour, (u, v) in centres.items():
+        d = np.hypot(uu - u, vv - v)
+        r = radii[colour] if isinstance(radii, dict) else radii
+        inside = d <= r
+        img[inside] = DISC_COLOURS[colour]
+        if soften:
+            rim = (d > r) & (d <= r + 1.5)
+            a = ((r + 1.5 - d[rim]) / 1.5)[:, None]
+            img[rim] = (a * np.array(DISC_COLOURS[colour]) + (1 - a) * background).astype(np.uint8)
+    return img[::-1].copy()                                  # hand over unflipped, as the sensor does

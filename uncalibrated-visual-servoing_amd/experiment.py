@@ -34,11 +34,13 @@ class ExperimentStatus(Enum):
 
 
 def detect4Circles(image):
-    """Feature extraction hook bound in this module's namespace like the reference (experiment.py:2, utils.py:81-144).
-    The OpenCV detector is out of scope; synthetic robots hand over an object that already knows its features."""
+    """Feature extraction hook bound in this module's namespace like the reference (experiment.py:2, utils.py:126-166).
+    Synthetic robots hand over an object that already knows its features; a camera frame (H x W x 3 uint8, as
+    UR10Simulation.getCameraImage returns it) goes through the centre-of-mass detector."""
     if hasattr(image, 'features'):
         return image.features()
-    raise NotImplementedError('no circle detector: bind experiment.detect4Circles to your perception front-end')
+    from .utils import detect4Circles as _detect
+    return _detect(image)
 
 
 _GPU_METHODS = (Method.KF, Method.MCKF, Method.IMCCKF, Method.GMCKF)
