@@ -154,6 +154,30 @@ def test_mckf_fixed_point_iterations_match_block_oracle(uvs, lanes):
         assert rel_err(out['p_final'].cpu().numpy()[0].reshape(8, 6, 6), ref['P_final']) <= 1e-9
 
 
+# ---------------------------------------------------------------------------------------------- the reference's tests/*.py
+@pytest.mark.parametrize('lanes', [0, -1])
+@pytest.mark.parametrize('name', golden_names('script_'))
+def test_replay_matches_reference_scripts(uvs, name, lanes):
+    """(2,6) and (6,6) filters of tests/kalman_{1,3}_feature(s).py and tests/mckf_{1,3}_feature(s).py (BASELINE.json configs[0]):
+    the streams those scripts produced go through the replay kernel; X per step, final P and the twist command must come back."""
+    g = load_golden(name)
+    meta = g['meta']
+    m, K, mask = meta['m'], meta['steps'], g['cmd_mask']
+    fp = uvs.engine.make_params(m, 6, meta['method'], meta['kernel_bw'] or 10.0, False, meta['dt'], 100.0, meta['gain'], g['desired'], False,
+                                lanes, K, meta['fpi_threshold'] or 0.1, max(meta['fpi_epoch_max'], 1))
+    T = 2
+    rep = lambda a: _cuda(np.repeat(a[:, :, None], T, axis=2))               # noqa: E731
+    out = uvs.engine.replay(fp, rep(g['f']), rep(g['dp_prev']), _cuda(np.tile(g['X0'], (T, 1))), final_state=True)
+    X = out['x'].cpu().numpy()
+    assert np.array_equal(X[:, :, 0], X[:, :, 1])
+    assert rel_err(X[g['X_steps'], :, 0], g['X']) <= 1e-10
+    cmd = out['dqcmd'].cpu().numpy()[:-1, :, 0]
+    assert rel_err(cmd[:, mask], g['dp_prev'][1:][:, mask]) <= 1e-8
+    assert rel_err(out['p_final'].cpu().numpy()[0].reshape(m, 6, 6), g['P_blocks'][-1]) <= 1e-9
+    assert np.array_equal(out['err'].cpu().numpy()[:, :, 0], g['f'][1:] - g['desired'])
+    assert int(out['status'].sum()) == 0 and int(out['k_done'][0]) == K
+
+
 # ---------------------------------------------------------------------------------------------- other shapes
 def _random_replay_case(m, n, K, T, seed):
     rng = np.random.default_rng(seed)

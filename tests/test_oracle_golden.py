@@ -112,3 +112,30 @@ def test_plant_goal_pose_projects_onto_desired():
     f = plant_ref.project(plant_ref.fkine_all(plant_ref.Q_GOAL)[5], discs)
     assert np.abs(f - plant_ref.DESIRED_F).max() < 1e-9
     assert np.abs(discs[:, 2]).max() < 1e-12                      # discs lie on the floor
+
+
+# ---------------------------------------------------------------------------------------------- the reference's tests/*.py
+SCRIPTS = golden_names('script_')
+
+
+def test_script_fixture_inventory():
+    assert SCRIPTS == ['script_kalman_1_as_committed', 'script_kalman_1_initial_guess', 'script_kalman_3', 'script_mckf_1', 'script_mckf_3']
+
+
+@pytest.mark.parametrize('name', SCRIPTS)
+def test_block_replay_matches_reference_scripts(name):
+    """Streams recorded while the reference's own tests/*.py ran (oracle/gen_golden_scripts.py): (m, n) = (2, 6) and (6, 6), KF with
+    P = (I - KH) P (kalman_*:126/132) and fixed-point MCKF, regressing on the camera-twist command.  BASELINE.json configs[0]."""
+    g = load_golden(name)
+    meta = g['meta']
+    out = rmckf_block.run_replay(g['f'], g['dp_prev'], g['X0'], g['desired'], meta['gain'], method=meta['method'],
+                                 kernel_bw=meta['kernel_bw'] or 10.0, fpi_threshold=meta['fpi_threshold'],
+                                 fpi_epoch_max=max(meta['fpi_epoch_max'], 1))
+    K, mask = meta['steps'], g['cmd_mask']
+    assert len(out['X']) == K
+    assert rel_err(out['X'][g['X_steps']], g['X']) <= 1e-12
+    assert rel_err(out['dq_cmd'][:-1][:, mask], g['dp_prev'][1:][:, mask]) <= 1e-10      # command of step k = regressor of step k+1
+    assert int(g['P_steps'][-1]) == K - 1 and rel_err(out['P_final'], g['P_blocks'][-1]) <= 1e-11
+    assert float(g['P_offblock_max']) == 0.0
+    if meta['method'] == 'MCKF':
+        assert np.array_equal(out['fpi_iterations'], g['epochs']) and g['epochs'].max() >= 2
