@@ -178,6 +178,38 @@ def test_replay_matches_reference_scripts(uvs, name, lanes):
     assert int(out['status'].sum()) == 0 and int(out['k_done'][0]) == K
 
 
+def test_baseline_config_1_batch(uvs):
+    """BASELINE.json configs[0] as a closed loop: one feature (m = 2), KF, WHITE_NOISE std 1, 100 trials
+    with seeds 123456 + t, analytic initial guess; kernel (2,6) against the per-row oracle on the oracle's own plant."""
+    from oracle import noise_ref, plant_ref, rmckf_block, rmckf_dense
+    T, dt, t_max, gain = 100, 0.05, 15, 0.2
+    desired = np.array([128.0, 128.0])
+    plant = uvs.SyntheticPlant.ur10(desired)
+    discs = plant_ref.place_discs(desired)
+    assert np.allclose(discs, plant.points, rtol=0, atol=1e-15)
+    rng = np.random.default_rng(7)
+    q0 = plant_ref.Q_GOAL + 0.05 * rng.standard_normal((T, 6))
+    K = len(uvs.engine.loop_clock(dt, t_max))
+    noise = uvs.noise_batch(uvs.NoiseType.WHITE_NOISE, {'std': 1.0}, 123456 + np.arange(T), 2, K)        # (T, K, 2)
+    ref_stream = noise_ref.NoiseStreamRef(2, noise_ref.WHITE_NOISE, 123456 + 3, std=1.0)
+    assert np.array_equal(noise[3], ref_stream.take(K))
+    fp = uvs.engine.make_params(2, 6, 'KF', 10.0, False, dt, t_max, gain, desired, True)
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q'))
+    assert int(out['status'].sum()) == 0 and int(out['k_done'].min()) == K
+    worst = 0.0
+    for t in range(0, T, 9):
+        robot = plant_ref.PinholeUR10(dt, discs)
+        robot.start(q0[t])
+        x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 2, 6)
+        ref = rmckf_block.run_closed_loop(lambda q: plant_ref.project(plant_ref.fkine_all(q)[5], discs), q0[t], desired, noise[t], dt, t_max,
+                                          gain, x0, method='KF')
+        assert ref['status'] == 0
+        worst = max(worst, rel_err(out['err'].cpu().numpy()[:, :, t], ref['err']), rel_err(out['q'].cpu().numpy()[:, :, t], ref['q']),
+                    rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']))
+        assert rel_err(out['stats'].cpu().numpy()[t], rmckf_dense.trial_stats(ref['err'], ref['t'])) <= 1e-8
+    assert worst <= 1e-8
+
+
 # ---------------------------------------------------------------------------------------------- other shapes
 def _random_replay_case(m, n, K, T, seed):
     rng = np.random.default_rng(seed)
