@@ -166,6 +166,13 @@ typedef struct uvs_noise_params {
 } uvs_noise_params;
 
 /*
+ * numpy.random.PCG64(seed) for n integer seeds (< 2^64) at once, on the device: states[i] = (state_hi, state_lo, inc_hi, inc_lo)
+ * as SeedSequence + pcg64_set_seed produce them (numpy/random/bit_generator.pyx, src/pcg64); replaces constructing
+ * Generator(PCG64(seed + 10*i)) / PCG64(2*seed + i) one by one (noise.py:55-70).  seeds, states: device pointers.
+ */
+int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void *stream);
+
+/*
  * Noise streams of T trials generated on the device: out[t][k][i] is the k-th getNoise() value of feature i of
  * NoiseProfiler(m, type, seed_t, ...) (noise.py:81-118), where the trial's generators were seeded on the host:
  *   states [T][n_gen][4] uint64 (device) = (state_hi, state_lo, inc_hi, inc_lo) of PCG64(seed_t + 10*j) for j < gens*m

@@ -67,3 +67,27 @@ def test_closed_loop_on_device_noise_matches_host_noise(uvs):
     dev = np.abs(ea - eb).max(axis=(0, 1)) / np.abs(eb).max(axis=(0, 1))
     assert np.median(dev) < 1e-11 and dev.max() < 1e-6
     assert np.array_equal(a.status.cpu().numpy(), b.status.cpu().numpy())
+
+
+def test_device_seeding_matches_numpy(uvs):
+    """uvs_pcg64_seed_u64: SeedSequence + PCG64 seeding on the device against numpy's own generator states, including seeds
+    with a second entropy word (>= 2**32) and the wrap of seed + 10 j at 2**64."""
+    import torch
+    NT = uvs.NoiseType
+    rng = np.random.default_rng(3)
+    seeds = np.concatenate([np.array([0, 1, 2, 123456, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 63, 2 ** 64 - 1], dtype=np.uint64),
+                            rng.integers(0, 2 ** 63, 40, dtype=np.uint64), rng.integers(0, 2 ** 31, 40, dtype=np.uint64)])
+    st = torch.empty((len(seeds), 4), dtype=torch.int64, device='cuda')
+    sd = torch.as_tensor(seeds.view(np.int64), device='cuda')
+    uvs._lib.check(uvs.lib().uvs_pcg64_seed_u64(len(seeds), sd.data_ptr(), st.data_ptr(), None))
+    got = st.cpu().numpy().view(np.uint64)
+    for s, row in zip(seeds, got):
+        ref = np.random.PCG64(int(s)).state['state']
+        assert (int(row[0]) << 64) | int(row[1]) == ref['state'] and (int(row[2]) << 64) | int(row[3]) == ref['inc'], int(s)
+    assert np.array_equal(got, uvs.pcg.pcg64_states(seeds))
+    # the generator table of a mixture trial: seed + 10 j for 3 m generators, then 2 seed + i for the m selectors (noise.py:59,70)
+    trial_seeds = np.array([123456, 2 ** 64 - 7], dtype=np.uint64)
+    dev = uvs.noise_device.device_generator_states(NT.GAUSSIAN_BIMODAL, trial_seeds, 8).cpu().numpy().view(np.uint64)
+    with np.errstate(over='ignore'):
+        host = uvs.pcg.pcg64_states(uvs.noise_device.generator_seeds(NT.GAUSSIAN_BIMODAL, trial_seeds, 8))
+    assert dev.shape == (2, 32, 4) and np.array_equal(dev, host)

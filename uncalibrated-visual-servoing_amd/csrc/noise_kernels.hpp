@@ -40,6 +40,60 @@ struct Pcg64 {
     UVS_DEV double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
+// numpy's integer seed -> PCG64 stream, on the device.  SeedSequence (numpy/random/bit_generator.pyx): the seed's 32-bit words
+// (one, or two when seed >= 2^32) are hashed into a pool of 4 words, every pool word is mixed into every other, and
+// generate_state(4, uint64) hashes the pool out again; pcg64_set_seed then runs state = 0; step; state += initstate; step
+// with inc = (initseq << 1) | 1.  One generator per thread; a sweep needs half a million of them (noise.py:59,70).
+__global__ __launch_bounds__(256) void pcg64_seed_kernel(long long n, const unsigned long long *seeds, unsigned long long *states) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long seed = seeds[i];
+    const unsigned e0 = (unsigned)seed, e1 = (unsigned)(seed >> 32);
+    unsigned hc = 0x43b0d7e5u;
+    auto hashmix = [&hc](unsigned v) {
+        v ^= hc;
+        hc *= 0x931e8875u;
+        v *= hc;
+        return v ^ (v >> 16);
+    };
+    auto mix = [](unsigned x, unsigned y) {
+        const unsigned r = 0xca01f9ddu * x - 0x4973f715u * y;
+        return r ^ (r >> 16);
+    };
+    unsigned pool[4];
+    pool[0] = hashmix(e0);
+    pool[1] = hashmix(e1);                                          // a missing second word hashes as 0, and e1 == 0 then
+    pool[2] = hashmix(0u);
+    pool[3] = hashmix(0u);
+#pragma unroll
+    for (int src = 0; src < 4; ++src)
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst)
+            if (src != dst) pool[dst] = mix(pool[dst], hashmix(pool[src]));
+    unsigned hb = 0x8b51f9ddu, w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned d = pool[k & 3] ^ hb;
+        hb *= 0x58f38dedu;
+        d *= hb;
+        w[k] = d ^ (d >> 16);
+    }
+    const unsigned long long init_hi = w[0] | ((unsigned long long)w[1] << 32), init_lo = w[2] | ((unsigned long long)w[3] << 32);
+    const unsigned long long seq_hi = w[4] | ((unsigned long long)w[5] << 32), seq_lo = w[6] | ((unsigned long long)w[7] << 32);
+    const unsigned long long inc_hi = (seq_hi << 1) | (seq_lo >> 63), inc_lo = (seq_lo << 1) | 1ULL;
+    const unsigned long long MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
+    unsigned long long sl = inc_lo + init_lo;                        // (0 * mult + inc) + initstate
+    unsigned long long sh = inc_hi + init_hi + (sl < inc_lo ? 1ULL : 0ULL);
+    const unsigned long long lo = sl * ML;
+    unsigned long long hi = __umul64hi(sl, ML) + sl * MH + sh * ML;
+    const unsigned long long nlo = lo + inc_lo;
+    hi += inc_hi + (nlo < lo ? 1ULL : 0ULL);
+    states[4 * i + 0] = hi;
+    states[4 * i + 1] = nlo;
+    states[4 * i + 2] = inc_hi;
+    states[4 * i + 3] = inc_lo;
+}
+
 UVS_DEV double standard_normal(Pcg64 &g, const double *zig) {
     const double *fi = zig, *wi = zig + 256;
     const unsigned long long *ki = reinterpret_cast<const unsigned long long *>(zig + 512);

@@ -517,6 +517,13 @@ int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t
     return check_launch("noise_kernel");
 }
 
+int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void *stream) {
+    if (n <= 0 || !seeds || !states) return fail(UVS_ERR_ARG, "%s", "bad pcg64_seed arguments");
+    hipLaunchKernelGGL(uvs::pcg64_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n,
+                       (const unsigned long long *)seeds, (unsigned long long *)states);
+    return check_launch("pcg64_seed_kernel");
+}
+
 int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
     if (n <= 0 || !x || !y) return fail(UVS_ERR_ARG, "%s", "bad debug_math arguments");
     hipLaunchKernelGGL(uvs::debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, (long long)n, x, y);
