@@ -67,3 +67,16 @@ def test_results_csv_has_the_reference_format(uvs, tmp_path):
     # the MATLAB post-processing recomputes the statistics from these columns (results/plot_errorbar.m:39-84)
     from oracle.rmckf_dense import trial_stats
     assert rel_err(trial_stats(d - f, first['t'].values), res.stats.cpu().numpy()[0]) <= 1e-9
+
+
+def test_results_npz_sink(uvs, tmp_path):
+    cfg = _cfg(epoch=3)
+    res = uvs.batch.run_batch(cfg, cells=[1.0, 1.5], want=('err',))
+    path = uvs.batch.save_results_npz(res, cfg, str(tmp_path / 'sweep.npz'))
+    z = np.load(path)
+    assert list(z['experiment_id']) == list(range(6)) and list(z['rho']) == [1.0] * 3 + [1.5] * 3 and list(z['seed']) == [123456 + i for i in range(6)]
+    assert np.array_equal(z['stats'], res.stats.cpu().numpy()) and z['stats'].shape == (6, 3) and list(z['stats_columns']) == ['ise', 'iae', 'itae']
+    assert np.array_equal(z['stream_err'], res.streams['err'].cpu().numpy()) and z['stream_err'].shape == (299, 8, 6)
+    assert np.array_equal(z['status'], np.zeros(6)) and np.array_equal(z['k_done'], np.full(6, 299)) and len(z['t']) == 299
+    import json
+    assert json.loads(str(z['config']))['estimator']['method'] == 'GMCKF'

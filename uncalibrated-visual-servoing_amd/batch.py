@@ -190,3 +190,19 @@ def write_results_csv(result, cfg, plant, path):
         cols['kernel_bw'] = np.full(k, -1.0)                        # -1 unless MCKF (experiment.py:330)
         pd.DataFrame(data=cols).to_csv(path, mode='a', index=False, header=header)
         header = False
+
+
+def save_results_npz(result, cfg, path, streams=True):
+    """Compact sink for sweeps too large for the long-format CSV (65 536 trials x 299 rows x 41 columns is 6.7 GB of text):
+    per-trial rows (experiment_id, swept value, seed, status, k_done, ISE / IAE / ITAE norms, q_start), the clock, the config,
+    and -- if ``streams`` -- whatever per-step tensors the run kept, trial-fastest as on the device ([step][component][trial])."""
+    data = {'experiment_id': np.arange(result.lo, result.hi), 'cell': result.plan.cell[result.lo:result.hi],
+            'rho': result.plan.value[result.lo:result.hi], 'seed': result.plan.seed[result.lo:result.hi],
+            'q_start': result.plan.q_start[result.lo:result.hi], 't': np.asarray(result.t),
+            'status': result.status.cpu().numpy(), 'k_done': result.k_done.cpu().numpy(), 'stats': result.stats.cpu().numpy(),
+            'stats_columns': np.array(['ise', 'iae', 'itae']), 'config': json.dumps(cfg)}
+    if streams:
+        for name, tensor in result.streams.items():
+            data['stream_' + name] = tensor.cpu().numpy()
+    np.savez_compressed(path, **data)
+    return path
