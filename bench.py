@@ -117,6 +117,7 @@ def main():
     ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
     ap.add_argument('--trials', type=int, default=0, help='trials per GPU (default: the size BASELINE.json names for the config)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
+    ap.add_argument('--force-dist', action='store_true', help='run the multi-rank code path (process group, barrier, stats gather) even with one rank: RCCL smoke test on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
@@ -128,6 +129,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
+    dist_on = world > 1 or args.force_dist
 
     import uvs_amd
     from uvs_amd import batch, dist, engine
@@ -163,7 +165,7 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())              # gloo test mode: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if dist_on:
         import torch.distributed as td
         if args.backend == 'nccl':
             td.init_process_group('nccl', device_id=dev)         # RCCL over xGMI
@@ -231,10 +233,10 @@ def main():
 
     def one_step():
         launch()
-        return gather() if world > 1 else None
+        return gather() if dist_on else None
 
     def barrier():
-        if world > 1:
+        if dist_on:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -248,13 +250,13 @@ def main():
         e0.record()                                               # HIP events on the stream the kernel is launched on
         launch()
         e1.record()
-        if world > 1:
+        if dist_on:
             gathered = gather()
         kernel_ms.append((e0, e1))
     barrier()
     wall = time.perf_counter() - t0
     red_dev = dev if args.backend == 'nccl' else torch.device('cpu')
-    if world > 1:
+    if dist_on:
         w = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         td.all_reduce(w, op=td.ReduceOp.MAX)
         wall = float(w.item())
@@ -262,7 +264,7 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_ms]
 
     updates_per_launch = int(k_done.sum().item())                 # FAIL trials stop early; count what was actually computed
-    if world > 1:
+    if dist_on:
         u = torch.tensor([updates_per_launch], dtype=torch.int64, device=red_dev)
         td.all_reduce(u)
         total_updates = int(u.item())
@@ -298,7 +300,7 @@ def main():
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         td.destroy_process_group()
 
 
