@@ -373,7 +373,11 @@ dim3 grid_for(int64_t T, int L) { return dim3((unsigned)((T * L + 63) / 64)); }
 // Tuned closed-loop kernel: estimator, plant kind and "X stream wanted" are compile-time there.
 template <int M, int N, int LL, int METHOD, int PLANT>
 void launch_tuned2(bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
+#ifdef UVS_PV                          // experiment builds: number of covariance blocks per lane kept in registers at L = 2
+    constexpr int PV = (LL == 2 ? UVS_PV : M / LL);
+#else
     constexpr int PV = (LL == 2 ? M / LL / 2 : M / LL);      // L = 2 parks half of its blocks in LDS; 1 and 4 keep all in registers
+#endif
     if (xo) hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, METHOD, PLANT, PV, true>), g, dim3(64), 0, s, A);
     else hipLaunchKernelGGL((uvs::closed_loop_tuned_kernel<M, N, LL, METHOD, PLANT, PV, false>), g, dim3(64), 0, s, A);
 }
