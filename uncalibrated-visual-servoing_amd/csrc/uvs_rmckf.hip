@@ -12,6 +12,7 @@
 #include <cstring>
 #include "rmckf_device.hpp"
 #include "rmckf_tuned.hpp"
+#include "rmckf_replay_tuned.hpp"
 #include "noise_kernels.hpp"
 
 namespace uvs {
@@ -391,6 +392,26 @@ void launch_tuned(int method, bool linear, bool xo, dim3 g, hipStream_t s, const
     else launch_tuned2<M, N, LL, UVS_METHOD_KF, UVS_PLANT_LINEAR>(xo, g, s, A);
 }
 
+// Tuned replay kernel (rmckf_replay_tuned.hpp): estimator, "X stream wanted" and "control law wanted" are compile-time.
+#ifndef UVS_REPLAY_PV
+#define UVS_REPLAY_PV 2
+#endif
+#define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6)
+template <int M, int N, int METHOD>
+void launch_replay_tuned2(bool xo, bool cmd, dim3 g, hipStream_t s, const uvs::ReplayArgs &A) {
+    constexpr int PV = UVS_REPLAY_PV;
+    if (xo && cmd) hipLaunchKernelGGL((uvs::replay_tuned_kernel<M, N, METHOD, PV, true, true>), g, dim3(64), 0, s, A);
+    else if (xo) hipLaunchKernelGGL((uvs::replay_tuned_kernel<M, N, METHOD, PV, true, false>), g, dim3(64), 0, s, A);
+    else if (cmd) hipLaunchKernelGGL((uvs::replay_tuned_kernel<M, N, METHOD, PV, false, true>), g, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL((uvs::replay_tuned_kernel<M, N, METHOD, PV, false, false>), g, dim3(64), 0, s, A);
+}
+template <int M, int N>
+void launch_replay_tuned(int method, bool xo, bool cmd, dim3 g, hipStream_t s, const uvs::ReplayArgs &A) {
+    if (method == UVS_METHOD_GMCKF) launch_replay_tuned2<M, N, UVS_METHOD_GMCKF>(xo, cmd, g, s, A);
+    else if (method == UVS_METHOD_IMCCKF) launch_replay_tuned2<M, N, UVS_METHOD_IMCCKF>(xo, cmd, g, s, A);
+    else launch_replay_tuned2<M, N, UVS_METHOD_KF>(xo, cmd, g, s, A);
+}
+
 }  // namespace
 
 extern "C" {
@@ -470,6 +491,15 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     A.status = status; A.k_done = k_done;
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
+    // two lanes per filter (the default) at (8,6): tuned kernel; a negative lanes_per_filter forces the generic template
+    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF) && fp->lanes_per_filter >= 0 && L == 2;
+#define XR(M, N) \
+    if (!launched && tuned_ok && fp->m == M && fp->n == N) { \
+        launch_replay_tuned<M, N>(fp->method, x_out.base != nullptr, dqcmd_out.base != nullptr, grid_for(T, 2), s, A); \
+        launched = true; \
+    }
+    UVS_TUNED_REPLAY_SHAPES(XR)
+#undef XR
 #define X(M, N, LL) \
     if (!launched && fp->m == M && fp->n == N && L == LL) { \
         if (fp->method == UVS_METHOD_GMCKF) hipLaunchKernelGGL((uvs::replay_kernel<M, N, LL, UVS_METHOD_GMCKF>), grid_for(T, LL), dim3(64), 0, s, A); \

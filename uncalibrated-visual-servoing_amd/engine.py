@@ -92,7 +92,7 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     dev = q_start.device
     out = {}
     for key, comp in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)):
-        out[key] = alloc_stream(T, K, comp, layout, dev, zero=True) if key in want else None
+        out[key] = alloc_stream(T, K, comp, layout, dev) if key in want else None      # rows at and after k_done are unspecified
     out['stats'] = torch.zeros((T, 3), dtype=torch.float64, device=dev)
     out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
     out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -116,7 +116,7 @@ def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', fin
     dev = x0.device
     out = {}
     for key, comp in (('x', m * n), ('err', m), ('kappa', m), ('dqcmd', n)):
-        out[key] = alloc_stream(T, K, comp, layout, dev, zero=True) if key in want else None
+        out[key] = alloc_stream(T, K, comp, layout, dev) if key in want else None      # rows at and after k_done are unspecified
     out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
     out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
     out['x_final'] = torch.empty((T, m * n), dtype=torch.float64, device=dev) if final_state else None
