@@ -108,6 +108,54 @@ def cpu_baseline(q_starts, budget_trials_per_core=16):
 
 
 # ---------------------------------------------------------------------------------------------- main
+def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T, K, M, N, reps=4):
+    """Replay mode (SURVEY 8d kernel microbenchmark): the estimator (+ control law) over recorded feature / joint-delta streams,
+    the I/O north_star prices: read f and dq, write X and err.  Synthetic consistent streams f_{k+1} = f_k + J dq_k dt + noise built on
+    the device; reuses the closed-loop run's output buffers.  Reported next to, never as, the closed-loop `value`."""
+    import ctypes as C
+    dev = x_buf.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(987654)
+    rnd = lambda *shape: torch.randn(shape, device=dev, dtype=torch.float64, generator=g)      # noqa: E731
+    J = rnd(M, N, T) * 50
+    dq = rnd(K, N, T) * 0.2
+    f = torch.empty((K + 1, M, T), device=dev, dtype=torch.float64)
+    f[0] = 128 + 20 * rnd(M, T)
+    for k in range(K):
+        f[k + 1] = f[k] + torch.einsum('mnt,nt->mt', J, dq[k]) * 0.05 + rnd(M, T)
+    x0 = (J + 5 * rnd(M, N, T)).permute(2, 0, 1).reshape(T, M * N).contiguous()
+    del J
+    fp = engine.make_params(M, N, 'GMCKF', fp_closed.kernel_bw, bool(fp_closed.annealing), fp_closed.dt, fp_closed.dt * fp_closed.k_max, fp_closed.gain,
+                            list(fp_closed.desired)[:M], False, 0, K)
+    cmd_buf = engine.alloc_stream(T, K, N, 'kct', dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    k_done = torch.zeros(T, dtype=torch.int32, device=dev)
+    NV = uvs_amd._lib.NULL_VIEW
+    flat = uvs_amd._lib.View(x0.data_ptr(), x0.stride(0), 0, x0.stride(1))
+    out = {}
+    for name, cmd, b_alg in (('estimator_and_control_law', True, 8 * (2 * M + 2 * N + M * N)), ('estimator_only', False, 8 * (2 * M + N + M * N))):
+        ms = []
+        for _ in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = uvs_amd.lib().uvs_rmckf_replay_f64(C.byref(fp), T, engine.stream_view(f, 'kct'), engine.stream_view(dq, 'kct'), flat,
+                                                    engine.stream_view(x_buf, 'kct'), engine.stream_view(err_buf, 'kct'), NV,
+                                                    engine.stream_view(cmd_buf, 'kct') if cmd else NV, status.data_ptr(), k_done.data_ptr(), NV, NV,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            uvs_amd._lib.check(rc)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        avg = float(np.mean(ms[1:]))
+        updates = int(k_done.sum().item())
+        gbs = updates * b_alg / (avg * 1e-3) / 1e9
+        out[name] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s',
+                     'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item())}
+    out['kernel'] = 'replay_tuned_kernel<8,6,GMCKF,2,true,cmd>'
+    out['streams'] = 'read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update, [step][component][trial]'
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -117,6 +165,7 @@ def main():
     ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
     ap.add_argument('--trials', type=int, default=0, help='trials per GPU (default: the size BASELINE.json names for the config)')
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
+    ap.add_argument('--no-replay', action='store_true', help='skip the replay-mode (estimator kernel) side measurement')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-rank code path (process group, barrier, stats gather) even with one rank: RCCL smoke test on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
@@ -282,6 +331,9 @@ def main():
         tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2) and not args.stats_only:
             traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')     # rocprofv3 PMC, measured on exactly this launch shape
+        replay = None
+        if world == 1 and args.config == 2 and not args.no_replay and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
+            replay = replay_side_measurement(torch, engine, uvs_amd, fp, bufs['x'], bufs['err'], T, K, M, N)
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -295,6 +347,7 @@ def main():
                          'traffic': traffic, 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
             'cpu_baseline': cpu,
+            'replay': replay,
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},
