@@ -396,7 +396,7 @@ void launch_tuned(int method, bool linear, bool xo, dim3 g, hipStream_t s, const
 #ifndef UVS_REPLAY_PV
 #define UVS_REPLAY_PV 2
 #endif
-#define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6)
+#define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6) X(6, 6)
 template <int M, int N, int METHOD>
 void launch_replay_tuned2(bool xo, bool cmd, dim3 g, hipStream_t s, const uvs::ReplayArgs &A) {
     constexpr int PV = UVS_REPLAY_PV;
