@@ -4,13 +4,14 @@
 // Restated third-party algorithms (numpy is not vendored in the reference; requirements.txt:1 pins numpy==2.2.4):
 //   * PCG64 (numpy/random/src/pcg64/pcg64.h): 128-bit LCG state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc, output
 //     XSL-RR: rotr64(hi ^ lo, hi >> 58) of the *advanced* state; next_double = (u64 >> 11) * 2^-53.  Seeding (SeedSequence +
-//     pcg64_set_seed) happens on the host, vectorised, in pcg.py.
+//     pcg64_set_seed) is pcg64_seed_kernel below (pcg.py holds the same arithmetic in numpy as the host check).
 //   * Generator.uniform(low, high) = low + (high - low) * next_double;  Generator.normal(loc, scale) = loc + scale * z with z
 //     from the 256-layer ziggurat of numpy/random/src/distributions/distributions.c (random_standard_normal): tables
 //     fi / wi / ki shipped in data/ziggurat_normal.npz (tools/extract_ziggurat_tables.py), tail and wedge tests as there.
 // One lane owns one feature *pair* of one trial, because the outlier hold couples the two features of a pair
 // (noise.py:82-116); lanes of a wavefront hold consecutive trials so the trial-fastest output layout is written coalesced.
 #pragma once
+#include "rmckf_math.hpp"
 #include "rmckf_device.hpp"
 
 namespace uvs {
@@ -150,10 +151,20 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
     } else {
         const double V = -HALF_PI + PI * gens[0].next_double();
         const double W = -log(0.0 + 1.0 * gens[0].next_double());
-        if (p.beta == 0.0) {
-            x = (sin(p.alpha * V) / pow(cos(V), p.inv_alpha)) * pow(cos(V * p.one_minus_alpha) / W, p.expo);
-        } else if (p.alpha != 1.0) {
-            x = p.cms_S * sin(p.alpha * V + p.cms_B) / pow(cos(V), p.inv_alpha) * pow(cos(p.one_minus_alpha * V - p.cms_B) / W, p.expo);
+        if (p.alpha != 1.0) {
+            // sin(aV + B) / cos(V)^(1/a) * (cos((1-a)V - B) / W)^((1-a)/a), B = 0 and S = 1 when beta = 0 (noise.py:188-199).  The two powers
+            // are folded into one exponential, exp(e log(c2 / W) - log(c1) / a): three bounded-argument sincos (|angle| < 3 pi / 2), two logs
+            // and one exp instead of three trigonometric calls and two pow(); differs from the reference's evaluation by
+            // <= (|exponent| + 2) ulp (|exponent| <~ 40 even for the 1e-16 tails of cos V and W), inside the 2e-13 gate of the noise fixtures.
+            // A negative base (possible only with beta != 0) gives NaN through log exactly as numpy's pow does.
+            const bool sym = (p.beta == 0.0);
+            const double B = sym ? 0.0 : p.cms_B;
+            double s1, c1, s0, c0, s2, c2;
+            sincos_bounded(sym ? p.alpha * V : p.alpha * V + B, s1, c1);
+            sincos_bounded(V, s0, c0);
+            sincos_bounded(sym ? V * p.one_minus_alpha : p.one_minus_alpha * V - B, s2, c2);
+            const double e = exp(fma(p.expo, log(c2 / W), -p.inv_alpha * log(c0)));
+            x = sym ? s1 * e : p.cms_S * s1 * e;
         } else {
             const double sv = HALF_PI + p.beta * V;
             x = p.two_over_pi * (sv * tan(V) - p.beta * log((W * cos(V)) / sv));
