@@ -297,6 +297,17 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     }
     __syncthreads();                                               // lds_c is read by every lane
 
+    double nz_next[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) nz_next[r] = 0.0;
+    if (on_noise && K > 0) {
+        const double *pr = pn;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { nz_next[r] = *pr; pr += L * A.noise.sc; }
+        pn += A.noise.sk;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
+
     double t = fp.dt;
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true;
@@ -310,16 +321,17 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     for (int k = 0; k < K; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         UVS_STAMP(5);
-        // ---- noise load first (its latency hides under the kinematics)
+        // ---- measurement noise: this step's values were requested a whole step ago; request the next step's now.  vmcnt counts in
+        // order, so waiting for a load also waits for every older store: fetched at the top of the step that uses them, the loads sit
+        // behind the previous step's err / q stores and the wait in front of the row updates inherits their write latency.
         double nz[R];
-        if (on_noise) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz[r] = nz_next[r];
+        if (on_noise && k + 1 < K) {
             const double *pr = pn;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { nz[r] = *pr; pr += L * A.noise.sc; }
+            for (int r = 0; r < R; ++r) { nz_next[r] = *pr; pr += L * A.noise.sc; }
             pn += A.noise.sk;
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) nz[r] = 0.0;
         }
         // ---- plant: noise-free features of this lane's rows
         double z[R];
