@@ -151,7 +151,7 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
         gbs = updates * b_alg / (avg * 1e-3) / 1e9
         out[name] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s',
                      'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item())}
-    out['kernel'] = 'replay_tuned_kernel<8,6,GMCKF,2,true,cmd>'
+    out['kernel'] = 'estimator_and_control_law: replay_tuned_kernel<8,6,GMCKF,2,true,true> (2 lanes/filter); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true> (4 lanes/filter, 2 wavefronts/SIMD)'
     out['streams'] = 'read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update, [step][component][trial]'
     return out
 

@@ -239,3 +239,202 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
 }
 
 }  // namespace uvs
+
+namespace uvs {
+
+// Sum over the L lanes lane, lane ^ (64 / L), ... that hold one filter under the blocked mapping; every lane gets the bit-identical total
+// (butterfly through the LDS crossbar, ds_bpermute; used once or twice per step).
+template <int L>
+UVS_DEV double blocked_sum(double v) {
+#pragma unroll
+    for (int d = 64 / L; d < 64; d *= 2) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Estimator alone (no control law), L lanes per filter, whole state in registers, two wavefronts per SIMD.  Without the least-squares
+// solve the rows of a filter never talk to each other (except the finiteness probe and IMCC-KF's shared weight), so four lanes per
+// filter cost no redundant arithmetic, the per-lane state (2 covariance blocks + 2 rows of X = 54 doubles at (8,6)) fits a 256-register
+// budget, and a second wavefront on the SIMD issues its arithmetic under this one's stores: the replay becomes HBM-bound.
+// EOUT (err stream wanted) is compile-time like XOUT: the prefetched inputs are waited for with an in-order vmcnt that must let every
+// store issued after them stay in flight, and the compiler can only count stores it knows will be issued.
+template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT>
+__global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) {
+    static_assert((L == 2 || L == 4) && M % L == 0, "rows kernel: 2 or 4 lanes per filter");
+    constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;
+    // Lane -> (trial, sub) is blocked, not interleaved: lanes [sub * TPW, (sub + 1) * TPW) hold row group `sub` of TPW consecutive
+    // trials, so the four lanes of every quad store to adjacent addresses.  With the interleaved mapping of the least-squares kernels
+    // (partner lanes adjacent, for DPP) a quad scatters over L component rows and the same stores cost 3x as much here.
+    const unsigned lane = threadIdx.x;
+    const int sub = (int)(lane / TPW);
+    const long long wave_first = (long long)blockIdx.x * TPW;
+    const unsigned tl = lane % TPW;
+    const bool valid = wave_first + tl < A.T;
+    const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
+    const uvs_filter_params &fp = A.fp;
+    const int K = fp.steps;
+
+    const double *pf = A.f.at(trial, 1, sub);
+    const double *pd = A.dq.at(trial, 1, 0);
+    double *px = (XOUT && A.x_out.p) ? A.x_out.at(trial, 0, sub * N) : nullptr;
+    double *pe = (EOUT && A.err_out.p) ? A.err_out.at(trial, 0, sub) : nullptr;
+    double *pk = A.kappa_out.p ? A.kappa_out.at(trial, 0, sub) : nullptr;
+    const bool on_kappa = A.kappa_out.p != nullptr;
+
+    double f_prev[R], des[R], f_next[R], h_next[N], x[R][N], p[R][NP];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        des[r] = pick_sub<L>(&fp.desired[r * L], sub);
+        f_prev[r] = *A.f.at(trial, 0, r * L + sub);
+        f_next[r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) x[r][j] = *A.x0.at(trial, 0, (r * L + sub) * N + j);
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+#pragma unroll
+            for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = (l == j) ? 1.0 : 0.0;      // P = I (experiment.py:73)
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) h_next[j] = 0.0;                    // first_run: H = 0 (experiment.py:183-185)
+    if (K > 0) {
+        const double *pr = pf;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f_next[r] = *pr; pr += L * A.f.sc; }
+        pf += A.f.sk;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), see replay_tuned_kernel
+
+    int status = UVS_STATUS_SUCCESS, k_done = K;
+    bool alive = true;
+    for (int k = 0; k < K; ++k) {
+        double f[R], dq[N];
+#pragma unroll
+        for (int r = 0; r < R; ++r) f[r] = f_next[r];
+#pragma unroll
+        for (int j = 0; j < N; ++j) dq[j] = h_next[j];
+        if (k + 1 < K) {
+            const double *pr = pf;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { f_next[r] = *pr; pr += L * A.f.sc; }
+            const double *pj = pd;
+#pragma unroll
+            for (int j = 0; j < N; ++j) { h_next[j] = *pj; pj += A.dq.sc; }
+            pf += A.f.sk;
+            pd += A.dq.sk;
+        }
+        const double sigma = bandwidth(fp, k);
+        const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
+        double c_shared = 1.0;
+        if constexpr (METHOD == UVS_METHOD_IMCCKF) {
+            double ss = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(x[r][j], dq[j], pred);
+                const double nu = (f[r] - f_prev[r]) - pred;
+                ss = fma(nu, nu, ss);
+            }
+            c_shared = exp_nonpos(blocked_sum<L>(ss) * neg_half_inv_s2);
+        }
+        double kap[R], err[R];
+        double chk = 0.0;
+        double *pxr = px;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double zi = f[r] - f_prev[r];
+            f_prev[r] = f[r];
+            err[r] = f[r] - des[r];
+            double g[N];
+            double pred = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) pred = fma(x[r][j], dq[j], pred);
+            const double nu = zi - pred;
+#pragma unroll
+            for (int l = 0; l < N; ++l) p[r][Sym<N>::at(l, l)] += 1.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                double acc = p[r][Sym<N>::at(l, 0)] * dq[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) acc = fma(p[r][Sym<N>::at(l, j)], dq[j], acc);
+                g[l] = acc;
+            }
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
+            double gamma;
+            if constexpr (METHOD == UVS_METHOD_GMCKF) {
+                kap[r] = exp_nonpos((nu * nu) * neg_half_inv_s2);
+                const double d = kap[r] + fp.reg;
+                gamma = d * fast_rcp(fma(a, d, 1.0));
+            } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {
+                kap[r] = 1.0;
+                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
+            } else {
+                kap[r] = 1.0;
+                gamma = fast_rcp(a + 1.0);
+            }
+            const double step = gamma * nu;
+            const double beta = gamma * (2.0 - gamma * (a + 1.0));
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                x[r][j] = fma(g[j], step, x[r][j]);
+                chk = fma(x[r][j], 0.0, chk);
+            }
+            if constexpr (XOUT) {
+                double *pcx = pxr;
+#pragma unroll
+                for (int j = 0; j < N; ++j) { *pcx = x[r][j]; pcx += A.x_out.sc; }
+                pxr += L * N * A.x_out.sc;
+            }
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                const double w = beta * g[l];
+#pragma unroll
+                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = fma(-w, g[j], p[r][Sym<N>::at(l, j)]);
+            }
+        }
+        if constexpr (XOUT) px += A.x_out.sk;
+        chk = blocked_sum<L>(chk);
+        if (alive && !(chk == 0.0)) {
+            alive = false;
+            status = UVS_STATUS_FAIL;
+            k_done = k;
+        }
+        // no early exit when every trial of the wavefront has failed: a path that skips the err stores would make the compiler's
+        // in-order vmcnt for the prefetched inputs count only the X stores and wait for the rest, every step
+        if constexpr (EOUT) {
+            double *po = pe;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { *po = err[r]; po += L * A.err_out.sc; }
+            pe += A.err_out.sk;
+        }
+        if (on_kappa) {
+            double *po = pk;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { *po = kap[r]; po += L * A.kappa_out.sc; }
+            pk += A.kappa_out.sk;
+        }
+    }
+
+    if (!valid) return;
+    if (sub == 0) {
+        if (A.status) A.status[trial] = status;
+        if (A.k_done) A.k_done[trial] = k_done;
+    }
+    if (A.x_final.on()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) *A.x_final.at(trial, 0, (r * L + sub) * N + j) = x[r][j];
+    }
+    if (A.p_final.on()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int l = 0; l < N; ++l)
+#pragma unroll
+                for (int j = 0; j < N; ++j) *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) = p[r][Sym<N>::at(l, j)];
+    }
+}
+
+}  // namespace uvs

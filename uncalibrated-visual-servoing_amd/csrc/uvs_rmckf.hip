@@ -415,6 +415,21 @@ void launch_replay_tuned(int method, bool xo, bool cmd, dim3 g, hipStream_t s, c
     else launch_replay_tuned2<M, N, UVS_METHOD_KF>(xo, cmd, g, s, A);
 }
 
+// Estimator-only replay, four lanes per filter, state in registers, two wavefronts per SIMD (rmckf_replay_tuned.hpp).
+template <int M, int N>
+void launch_replay_rows(int method, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A) {
+    const dim3 g = grid_for(T, 4), b(64);
+#define UVS_ROWS(METHOD) \
+    if (xo && eo) hipLaunchKernelGGL((uvs::replay_rows_kernel<M, N, 4, METHOD, true, true>), g, b, 0, s, A); \
+    else if (xo) hipLaunchKernelGGL((uvs::replay_rows_kernel<M, N, 4, METHOD, true, false>), g, b, 0, s, A); \
+    else if (eo) hipLaunchKernelGGL((uvs::replay_rows_kernel<M, N, 4, METHOD, false, true>), g, b, 0, s, A); \
+    else hipLaunchKernelGGL((uvs::replay_rows_kernel<M, N, 4, METHOD, false, false>), g, b, 0, s, A);
+    if (method == UVS_METHOD_GMCKF) { UVS_ROWS(UVS_METHOD_GMCKF) }
+    else if (method == UVS_METHOD_IMCCKF) { UVS_ROWS(UVS_METHOD_IMCCKF) }
+    else { UVS_ROWS(UVS_METHOD_KF) }
+#undef UVS_ROWS
+}
+
 }  // namespace
 
 extern "C" {
@@ -495,7 +510,14 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
     // two lanes per filter (the default) at (8,6): tuned kernel; a negative lanes_per_filter forces the generic template
-    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF) && fp->lanes_per_filter >= 0 && L == 2;
+    const bool tuned_method = fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF;
+    const bool tuned_ok = tuned_method && fp->lanes_per_filter >= 0 && L == 2;
+    // without the commanded dq there is no least-squares solve and nothing couples a filter's rows: four lanes per filter, state in
+    // registers, two wavefronts per SIMD (library default, or lanes_per_filter = 4)
+    if (tuned_method && !dqcmd_out.base && fp->m == 8 && fp->n == 6 && (fp->lanes_per_filter == 0 || fp->lanes_per_filter == 4)) {
+        launch_replay_rows<8, 6>(fp->method, x_out.base != nullptr, err_out.base != nullptr, T, s, A);
+        launched = true;
+    }
 #define XR(M, N) \
     if (!launched && tuned_ok && fp->m == M && fp->n == N) { \
         launch_replay_tuned<M, N>(fp->method, x_out.base != nullptr, dqcmd_out.base != nullptr, grid_for(T, 2), s, A); \
