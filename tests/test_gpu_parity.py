@@ -63,6 +63,48 @@ def test_replay_matches_reference(uvs, name, lanes):
     assert int(out['status'].sum()) == 0 and int(out['k_done'][0]) == K
 
 
+@pytest.mark.parametrize('lanes', [0, 4])
+@pytest.mark.parametrize('name', [n for n in CLOSED if 'closed_mckf' not in n])
+def test_estimator_only_replay_matches_reference(uvs, name, lanes):
+    """No commanded dq requested: the library runs the register-resident estimator kernel (four lanes per filter, blocked lane mapping, two
+    wavefronts per SIMD).  Same gates as the full replay, ragged batch (35 trials = 2 full wavefronts of 16 + 3), and agreement with the
+    two-lane kernel that also solves the control law."""
+    g = load_golden(name)
+    K = len(g['t'])
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    T = 35
+    rng = np.random.default_rng(11)
+    f = np.repeat(f_seq[:, :, None], T, axis=2)
+    f[1:, :, 1:] += rng.standard_normal((K, 8, T - 1))                        # other trials see other measurements
+    dq = np.repeat(g['dq_prev'][:, :, None], T, axis=2)
+    x0 = np.tile(g['X'][0], (T, 1))
+    out = uvs.engine.replay(_fp(uvs, g, lanes), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err', 'kappa'), final_state=True)
+    ref = uvs.engine.replay(_fp(uvs, g, 2), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err', 'kappa', 'dqcmd'), final_state=True)
+    X = out['x'].cpu().numpy()
+    assert rel_err(X[g['X_steps'], :, 0], g['X']) <= 1e-10
+    assert np.array_equal(out['err'].cpu().numpy()[:, :, 0], g['err'])
+    if int(g['P_steps'][-1]) == K - 1:
+        P = out['p_final'].cpu().numpy()[0].reshape(8, 6, 6)
+        assert rel_err(P, g['P_blocks'][-1]) <= 1e-10 and np.array_equal(P, np.transpose(P, (0, 2, 1)))
+    for key in ('x', 'err', 'kappa', 'x_final', 'p_final'):
+        assert rel_err(out[key].cpu().numpy(), ref[key].cpu().numpy()) <= 1e-12, key
+    assert int(out['status'].sum()) == 0 and np.all(out['k_done'].cpu().numpy() == K)
+
+
+def test_estimator_only_replay_fail_semantics(uvs):
+    g = load_golden('closed_gmckf_a1p5')
+    K, T, bad = 60, 20, 23
+    f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+    f = np.repeat(f_seq[:, :, None], T, axis=2)
+    f[bad + 1, 5, 17] = np.inf                                               # trial 17 sees a non-finite feature at step `bad`
+    out = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(np.repeat(g['dq_prev'][:K, :, None], T, axis=2)),
+                            _cuda(np.tile(g['X'][0], (T, 1))), want=('x', 'err'))
+    status, k_done = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
+    assert status[17] == 1 and k_done[17] == bad and status.sum() == 1 and np.all(np.delete(k_done, 17) == K)
+    X = out['x'].cpu().numpy()
+    assert np.array_equal(X[:, :, 0], X[:, :, 19]) and np.array_equal(X[:bad, :, 17], X[:bad, :, 0])
+
+
 # ---------------------------------------------------------------------------------------------- closed loop
 @pytest.mark.parametrize('lanes', LANES_86)
 @pytest.mark.parametrize('name', CLOSED)
