@@ -14,7 +14,7 @@ done
 cd $REPO
 f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1)
 cp $f $OUT/kernel_stats.csv
-(for tag in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do python3 tools/pmc_summary.py $OUT/pmc_$tag closed_loop; python3 tools/pmc_summary.py $OUT/pmc_$tag replay_tuned; python3 tools/pmc_summary.py $OUT/pmc_$tag noise_kernel; done) > $OUT/pmc_summary.txt
+(for tag in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do python3 tools/pmc_summary.py $OUT/pmc_$tag closed_loop; python3 tools/pmc_summary.py $OUT/pmc_$tag replay_tuned; python3 tools/pmc_summary.py $OUT/pmc_$tag replay_rows; python3 tools/pmc_summary.py $OUT/pmc_$tag noise_kernel; done) > $OUT/pmc_summary.txt
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 head -8 $OUT/kernel_stats.csv | cut -c1-200
 cat $OUT/pmc_summary.txt
