@@ -22,7 +22,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'libuvs_rmckf.so')
     if not os.path.exists(lib):
         import subprocess
-        subprocess.run(['make', '-C', os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'csrc')], check=True)
+        subprocess.run(['make', '-j', str(os.cpu_count() or 4), '-C', os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'csrc')], check=True)
 
 
 def golden_names(prefix):

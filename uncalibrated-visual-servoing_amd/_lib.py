@@ -75,7 +75,7 @@ def build(force=False):
     """Compile libuvs_rmckf.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.run(['make', '-C', CSRC], check=True)
+    subprocess.run(['make', '-j', str(os.cpu_count() or 4), '-C', CSRC], check=True)      # one translation unit per kernel family
     return LIB_PATH
 
 

@@ -1,0 +1,46 @@
+// Host-side launch functions, one translation unit per kernel family so that the library builds in parallel (make -j):
+// the C ABI (uvs_rmckf.hip) validates arguments and asks each family in turn; a launcher returns false when it has no
+// instantiation for the request.  The shape tables live here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "rmckf_device.hpp"
+
+// (m, n, lanes-per-filter) instantiations of the generic templates; the first listed L of a shape is its default.
+#ifdef UVS_QUICK                      // experiment builds (make quick): the headline shape only, compiles in seconds
+#define UVS_SHAPES_A(X) X(8, 6, 2)
+#define UVS_SHAPES_B(X)
+#define UVS_TUNED_SHAPES_A(X) X(8, 6, 2)
+#define UVS_TUNED_SHAPES_B(X)
+#else
+#define UVS_SHAPES_A(X) X(8, 6, 2) X(8, 6, 1) X(8, 6, 4) X(8, 6, 8) X(2, 6, 1)
+#define UVS_SHAPES_B(X) X(6, 6, 2) X(6, 6, 1) X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)
+#define UVS_TUNED_SHAPES_A(X) X(8, 6, 2) X(6, 6, 2)
+#define UVS_TUNED_SHAPES_B(X) X(8, 6, 1) X(8, 6, 4)
+#endif
+#define UVS_SHAPES(X) UVS_SHAPES_A(X) UVS_SHAPES_B(X)
+#define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6) X(6, 6)
+
+namespace uvs_launch {
+
+inline dim3 grid_for(int64_t T, int L) { return dim3((unsigned)((T * L + 63) / 64)); }
+
+// tuned closed loop (rmckf_tuned.hpp): method in {KF, IMCCKF, GMCKF}
+bool closed_tuned_a(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+bool closed_tuned_b(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+// generic templates (rmckf_generic.hpp)
+bool closed_generic_a(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+bool closed_generic_b(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+bool replay_generic_a(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+bool replay_generic_b(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+bool step_generic(int m, int n, int L, int64_t T, hipStream_t s, const uvs::StepArgs &A);
+// tuned replay (rmckf_replay_tuned.hpp): two lanes per filter with the control law, four lanes per filter for the estimator alone
+bool replay_tuned(int m, int n, int method, bool xo, bool cmd, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+bool replay_rows(int m, int n, int method, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+// everything else
+void stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *stats, hipStream_t s);
+void debug_math(int which, long long n, const double *x, double *y, hipStream_t s);
+void noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s);
+void pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s);
+
+}  // namespace uvs_launch

@@ -1,0 +1,31 @@
+// Single-step kernel (state in HBM), statistics, math test hook, noise generator and PCG64 seeding.
+#include "launchers.hpp"
+#include "rmckf_generic.hpp"
+#include "misc_kernels.hpp"
+#include "noise_kernels.hpp"
+
+bool uvs_launch::step_generic(int m, int n, int L, int64_t T, hipStream_t s, const uvs::StepArgs &A) {
+#define X(M, N, LL) \
+    if (m == M && n == N && L == LL) { hipLaunchKernelGGL((uvs::step_kernel<M, N, LL, 0>), grid_for(T, LL), dim3(64), 0, s, A); return true; }
+    UVS_SHAPES(X)
+#undef X
+    return false;
+}
+
+void uvs_launch::stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(uvs::stats_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, T, K, m, err, t, k_done, out);
+}
+
+void uvs_launch::debug_math(int which, long long n, const double *x, double *y, hipStream_t s) {
+    hipLaunchKernelGGL(uvs::debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, which, n, x, y);
+}
+
+void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+    uvs::NoiseArgs A{np, T, states, zig, out};
+    const long long lanes = T * (np.m / 2);
+    hipLaunchKernelGGL(uvs::noise_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, A);
+}
+
+void uvs_launch::pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s) {
+    hipLaunchKernelGGL(uvs::pcg64_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, seeds, states);
+}
