@@ -195,7 +195,8 @@ def write_results_csv(result, cfg, plant, path):
 def save_results_npz(result, cfg, path, streams=True):
     """Compact sink for sweeps too large for the long-format CSV (65 536 trials x 299 rows x 41 columns is 6.7 GB of text):
     per-trial rows (experiment_id, swept value, seed, status, k_done, ISE / IAE / ITAE norms, q_start), the clock, the config,
-    and -- if ``streams`` -- whatever per-step tensors the run kept, trial-fastest as on the device ([step][component][trial])."""
+    and -- if ``streams`` -- whatever per-step tensors the run kept, trial-fastest as on the device ([step][component][trial]).
+    For a FAILed trial only the first ``k_done`` rows of a stream are meaningful (the reference trims its logs there, experiment.py:345-352)."""
     data = {'experiment_id': np.arange(result.lo, result.hi), 'cell': result.plan.cell[result.lo:result.hi],
             'rho': result.plan.value[result.lo:result.hi], 'seed': result.plan.seed[result.lo:result.hi],
             'q_start': result.plan.q_start[result.lo:result.hi], 't': np.asarray(result.t),
