@@ -150,10 +150,8 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
     x0 = None
     if not p['initial_guess']:
         x0 = torch.as_tensor(np.asarray(p['x0'], float).reshape(1, m * n).repeat(Tl, 0), device=dev)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
     out = engine.closed_loop(fp, plant.to_struct(), q0, noise_tensor, x0, want=want)
-    stop.record()
+    start, stop = out['events']                                     # HIP events around the kernel launch (output allocation excluded)
     stop.synchronize()
     return BatchResult(plan, lo, hi, t_log, out['stats'], out['status'], out['k_done'],
                        {k: out[k] for k in ('x', 'err', 'q', 'f', 'dq') if out.get(k) is not None}, noise_tensor,

@@ -99,13 +99,17 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     out['x_final'] = torch.empty((T, m * n), dtype=torch.float64, device=dev) if final_state else None
     out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
     flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)           # around the launch only: the
+    start.record()                                                                                     # allocations above are not kernel time
     rc = _lib.lib().uvs_rmckf_closed_loop_f64(
         C.byref(fp), C.byref(plant_struct), T, flat(q_start), stream_view(noise, layout), flat(x0),
         stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['q'], layout),
         stream_view(out['f'], layout), stream_view(out['dq'], layout),
         out['stats'].data_ptr(), out['status'].data_ptr(), out['k_done'].data_ptr(),
         flat(out['x_final']), flat(out['p_final']), _stream())
+    stop.record()
     _lib.check(rc)
+    out['events'] = (start, stop)
     return out
 
 
