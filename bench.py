@@ -89,10 +89,29 @@ def _cpu_trial(args):
     return out['k_done'], time.perf_counter() - t0
 
 
-def cpu_baseline(q_starts, budget_trials_per_core=16):
+def available_cores():
+    """Cores this process may really use: the scheduler affinity, cut down to the cgroup CPU quota when the container has one
+    (a 256-way affinity mask over a 16-core quota would otherwise report 256 'cores' running at a sixteenth of their speed)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]            # cgroup v2
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                                          # cgroup v1
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                cores = max(1, min(cores, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
+def cpu_baseline(q_starts, budget_trials_per_core=256):
     """Dense numpy restatement of the reference loop (oracle/rmckf_dense.py, op-for-op experiment.py:125-343) on all host cores."""
     os.environ['OPENBLAS_NUM_THREADS'] = '1'
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = available_cores()
     n_trials = min(len(q_starts), budget_trials_per_core * cores)
     jobs = [(123456 + i, q_starts[i]) for i in range(n_trials)]
     t0 = time.perf_counter()
@@ -103,7 +122,7 @@ def cpu_baseline(q_starts, budget_trials_per_core=16):
     single = updates / sum(r[1] for r in res)                     # per-process rate (what one reference process achieves)
     return {'value': updates / wall, 'unit': 'updates/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_trials} trials x 299 steps of config 2 through oracle/rmckf_dense.py (dense numpy, OPENBLAS_NUM_THREADS=1, '
-                      f'one process per core, noise pre-drawn); os.cpu_count()={os.cpu_count()}',
+                      f'one process per core, noise pre-drawn); os.cpu_count()={os.cpu_count()}, affinity={len(os.sched_getaffinity(0))}, usable (cgroup quota)={cores}',
             'per_process_updates_per_s': single}
 
 
@@ -198,7 +217,7 @@ def main():
     K = len(t_log)
 
     # ---- everything that forks happens before the GPU is touched
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = available_cores()
     workers = max(1, cores // max(1, world))
     cpu = None
     assert not (args.host_noise and args.config != 2), '--host-noise is wired for config 2 only'
