@@ -146,6 +146,8 @@ int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double
         return fail(UVS_ERR_ARG, "%s", "all step buffers are required");
     uvs::StepArgs A{*fp, T, X, P, f, f_old, dq_prev, first, k, dq_out, err_out, kappa_out, status};
     hipStream_t s = (hipStream_t)stream;
+    // the single-step kernel selects the estimator at run time (MCKF included): at (8,6) its two-lane form spills to scratch, four lanes fit
+    if (fp->lanes_per_filter == 0 && fp->m == 8 && fp->n == 6) L = 4;
     const bool launched = step_generic(fp->m, fp->n, L, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
     return check_launch("step_kernel");
