@@ -91,3 +91,18 @@ def test_device_seeding_matches_numpy(uvs):
     with np.errstate(over='ignore'):
         host = uvs.pcg.pcg64_states(uvs.noise_device.generator_seeds(NT.GAUSSIAN_BIMODAL, trial_seeds, 8))
     assert dev.shape == (2, 32, 4) and np.array_equal(dev, host)
+
+
+@pytest.mark.parametrize('alpha,beta', [(0.8, 0.0), (0.8, -0.7), (1.7, 0.3), (1.95, 0.0), (0.3, 1.0)])
+def test_device_cms_matches_host_generator_outside_the_fixtures(uvs, alpha, beta):
+    """Chambers-Mallows-Stuck branch (both powers folded into one exponential on the device) against the host NoiseProfiler (numpy,
+    formula as written in noise.py:188-199) for index / skewness pairs the reference fixtures do not cover, incl. alpha < 1."""
+    params = dict(alpha=alpha, beta=beta, gamma=1.3, delta=-0.4)
+    seeds = [77, 78, 123456]
+    K = 400
+    dev = uvs.engine.as_tkc(uvs.noise_device.generate(uvs.NoiseType.ALPHA_STABLE, params, seeds, 8, K), 'kct').cpu().numpy()
+    host = uvs.noise_batch(uvs.NoiseType.ALPHA_STABLE, params, seeds, 8, K)
+    finite = np.isfinite(host)
+    assert finite.mean() > 0.999 and np.array_equal(np.isfinite(dev), finite)
+    scale = np.maximum(np.abs(host[finite]), 1e-3)                           # delta shifts values through zero: relative to max(|x|, 1e-3)
+    assert np.max(np.abs(dev[finite] - host[finite]) / scale) <= 5e-13
