@@ -174,12 +174,13 @@ int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void 
 
 /*
  * Noise streams of T trials generated on the device: out[t][k][i] is the k-th getNoise() value of feature i of
- * NoiseProfiler(m, type, seed_t, ...) (noise.py:81-118), where the trial's generators were seeded on the host:
+ * NoiseProfiler(m, type, seed_t, ...) (noise.py:81-118), from the states of the trial's generators (uvs_pcg64_seed_u64 above):
  *   states [T][n_gen][4] uint64 (device) = (state_hi, state_lo, inc_hi, inc_lo) of PCG64(seed_t + 10*j) for j < gens*m
  *          (noise.py:66-70) followed, for the mixtures, by PCG64(2*seed_t + i) for i < m (noise.py:55-59);
  *   zig    768 doubles (device): numpy's ziggurat tables fi[256], wi[256], ki[256] (ki as raw uint64 bits).
  * Uniform, normal and mixture streams reproduce numpy bit for bit (tail samples of the normal to 1-2 ulp); Cauchy and the
- * Chambers-Mallows-Stuck transforms agree to a few ulp (device libm vs host libm).
+ * Chambers-Mallows-Stuck transforms agree to <= 5e-13 relative (device libm vs host libm; the CMS powers are folded into one
+ * exponential, which costs up to ~40 ulp in the far tails).
  */
 int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream);
 
