@@ -111,58 +111,19 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
             const double zi = f[r] - f_prev[r];                  // measurement Z (experiment.py:170-177)
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];                              // experiment.py:302
-            double x[N], g[N], pb[NP];
+            double x[N], pb[NP];
 #pragma unroll
             for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
 #pragma unroll
             for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-            double pred = 0.0;
+            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
 #pragma unroll
-            for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
-            const double nu = zi - pred;                         // innovation (experiment.py:274)
-#pragma unroll
-            for (int l = 0; l < N; ++l) pb[Sym<N>::at(l, l)] += 1.0;             // P + Q (experiment.py:167)
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                double acc = pb[Sym<N>::at(l, 0)] * dq[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], dq[j], acc);
-                g[l] = acc;
-            }
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
-            double gamma;
-            if constexpr (METHOD == UVS_METHOD_GMCKF) {
-                kap[r] = exp_nonpos((nu * nu) * neg_half_inv_s2);                // utils.py:171-172
-                const double d = kap[r] + fp.reg;                // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
-                gamma = d * fast_rcp(fma(a, d, 1.0));
-            } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {  // experiment.py:262-264
-                kap[r] = 1.0;
-                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
-            } else {                                             // KF (experiment.py:192)
-                kap[r] = 1.0;
-                gamma = fast_rcp(a + 1.0);
-            }
-            const double step = gamma * nu;
-            const double beta = gamma * (2.0 - gamma * (a + 1.0));
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                x[j] = fma(g[j], step, x[j]);                    // X + K (Z - H X) (experiment.py:291)
-                chk = fma(x[j], 0.0, chk);
-                lds_x[r * N + j][lane] = x[j];
-            }
+            for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
             if constexpr (XOUT) {
                 double *pcx = pxr;
 #pragma unroll
                 for (int j = 0; j < N; ++j) { *pcx = x[j]; pcx += A.x_out.sc; }
                 pxr += L * N * A.x_out.sc;
-            }
-#pragma unroll
-            for (int l = 0; l < N; ++l) {                        // Joseph update with R = 1: P -= beta g g^T
-                const double w = beta * g[l];
-#pragma unroll
-                for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
             }
 #pragma unroll
             for (int e = 0; e < NP; ++e) {
@@ -344,53 +305,12 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
             const double zi = f[r] - f_prev[r];
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];
-            double g[N];
-            double pred = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) pred = fma(x[r][j], dq[j], pred);
-            const double nu = zi - pred;
-#pragma unroll
-            for (int l = 0; l < N; ++l) p[r][Sym<N>::at(l, l)] += 1.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                double acc = p[r][Sym<N>::at(l, 0)] * dq[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) acc = fma(p[r][Sym<N>::at(l, j)], dq[j], acc);
-                g[l] = acc;
-            }
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
-            double gamma;
-            if constexpr (METHOD == UVS_METHOD_GMCKF) {
-                kap[r] = exp_nonpos((nu * nu) * neg_half_inv_s2);
-                const double d = kap[r] + fp.reg;
-                gamma = d * fast_rcp(fma(a, d, 1.0));
-            } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {
-                kap[r] = 1.0;
-                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
-            } else {
-                kap[r] = 1.0;
-                gamma = fast_rcp(a + 1.0);
-            }
-            const double step = gamma * nu;
-            const double beta = gamma * (2.0 - gamma * (a + 1.0));
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                x[r][j] = fma(g[j], step, x[r][j]);
-                chk = fma(x[r][j], 0.0, chk);
-            }
+            rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
             if constexpr (XOUT) {
                 double *pcx = pxr;
 #pragma unroll
                 for (int j = 0; j < N; ++j) { *pcx = x[r][j]; pcx += A.x_out.sc; }
                 pxr += L * N * A.x_out.sc;
-            }
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                const double w = beta * g[l];
-#pragma unroll
-                for (int j = l; j < N; ++j) p[r][Sym<N>::at(l, j)] = fma(-w, g[j], p[r][Sym<N>::at(l, j)]);
             }
         }
         if constexpr (XOUT) px += A.x_out.sk;

@@ -103,6 +103,70 @@ UVS_DEV double pick_sub(const double *v, int sub) {
     return (sub & 2) ? hi : lo;
 }
 
+// One row of the block-form estimator on a lane's registers: predict P_i + Q, innovation, correntropy weight, gain,
+// state update, rank-1 Joseph downdate.  x: row i of X; pb: its packed covariance block; dq: the regressor (the previous command);
+// zi: the row's measurement f_i - f_old_i.  chk accumulates 0 * x so that it turns NaN as soon as an entry of X is non-finite.
+// Shared by the tuned closed-loop kernel and both tuned replay kernels.
+template <int N, int METHOD>
+UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
+                       double reg, double &kap, double &chk) {
+    double g[N];
+    double pred = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
+    const double nu = zi - pred;                                 // innovation (experiment.py:274)
+#ifdef UVS_ABLATE_ROWS
+#pragma unroll
+    for (int l = 0; l < N; ++l) g[l] = pb[Sym<N>::at(l, l)] * dq[l];
+#else
+#pragma unroll
+    for (int l = 0; l < N; ++l) pb[Sym<N>::at(l, l)] += 1.0;     // P + Q (experiment.py:167)
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        double acc = pb[Sym<N>::at(l, 0)] * dq[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], dq[j], acc);
+        g[l] = acc;
+    }
+#endif
+    double a = 0.0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
+    double gamma;
+    if constexpr (METHOD == UVS_METHOD_GMCKF) {
+#ifdef UVS_ABLATE_EXP
+        kap = fast_rcp(fma(nu * nu, -neg_half_inv_s2, 1.0));
+#else
+        kap = exp_nonpos((nu * nu) * neg_half_inv_s2);           // utils.py:171-172
+#endif
+        const double d = kap + reg;                              // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
+        gamma = d * fast_rcp(fma(a, d, 1.0));
+    } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {          // K = c P H^T (c H P H^T + R)^-1 (experiment.py:262-264)
+        kap = 1.0;
+        gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
+    } else {                                                     // KF (experiment.py:192)
+        kap = 1.0;
+        gamma = fast_rcp(a + 1.0);
+    }
+    const double step = gamma * nu;
+    const double beta = gamma * (2.0 - gamma * (a + 1.0));
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        x[j] = fma(g[j], step, x[j]);                            // X + K (Z - H X) (experiment.py:291)
+        chk = fma(x[j], 0.0, chk);
+    }
+#ifndef UVS_ABLATE_ROWS
+#pragma unroll
+    for (int l = 0; l < N; ++l) {                                // Joseph update with R = 1: P -= beta g g^T
+        const double w = beta * g[l];
+#pragma unroll
+        for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
+    }
+#else
+    pb[0] = fma(-beta, g[0], pb[0]);
+#endif
+}
+
 // Householder QR least squares, rows interleaved over the L lanes of a filter: local row r of lane s is global row r*L + s.
 // In column c the local row m = c / L is the pivot row on lane c % L, an ordinary "below" row on lanes > c % L and already
 // finished on lanes < c % L; rows r > m are below the pivot on every lane -- so all lanes run the same unrolled code and only
@@ -481,54 +545,14 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             const double fi = z[r] + nz[r];                      // noisy feature (experiment.py:134-135)
             const double zi = fi - f_prev[r];                    // measurement Z (experiment.py:170-177)
             f_prev[r] = fi;
-            double x[N], g[N], pb[NP];
+            double x[N], pb[NP];
 #pragma unroll
             for (int j = 0; j < N; ++j) x[j] = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
 #pragma unroll
             for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-            double pred = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
-            const double nu = zi - pred;                         // innovation (experiment.py:274)
-#ifdef UVS_ABLATE_ROWS
-#pragma unroll
-            for (int l = 0; l < N; ++l) g[l] = pb[Sym<N>::at(l, l)] * dq[l];
-#else
-#pragma unroll
-            for (int l = 0; l < N; ++l) pb[Sym<N>::at(l, l)] += 1.0;             // P + Q (experiment.py:167)
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                double acc = pb[Sym<N>::at(l, 0)] * dq[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], dq[j], acc);
-                g[l] = acc;
-            }
-#endif
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
-            double gamma;
-            if constexpr (METHOD == UVS_METHOD_GMCKF) {
-#ifdef UVS_ABLATE_EXP
-                kap[r] = fast_rcp(fma(nu * nu, -neg_half_inv_s2, 1.0));
-#else
-                kap[r] = exp_nonpos((nu * nu) * neg_half_inv_s2);   // utils.py:171-172
-#endif
-                const double d = kap[r] + fp.reg;                // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
-                gamma = d * fast_rcp(fma(a, d, 1.0));
-            } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {  // K = c P H^T (c H P H^T + R)^-1 (experiment.py:262-264)
-                kap[r] = 1.0;
-                gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
-            } else {                                             // KF (experiment.py:192)
-                kap[r] = 1.0;
-                gamma = fast_rcp(a + 1.0);
-            }
-            const double step = gamma * nu;
-            const double beta = gamma * (2.0 - gamma * (a + 1.0));
+            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                x[j] = fma(g[j], step, x[j]);                    // X + K (Z - H X) (experiment.py:291)
-                chk = fma(x[j], 0.0, chk);
                 if constexpr (XREG) xr[r][j] = x[j];
                 else lds_x[r * N + j][lane] = x[j];
             }
@@ -543,16 +567,6 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                     pxr += L * N * A.x_out.sc;
                 }
             }
-#ifndef UVS_ABLATE_ROWS
-#pragma unroll
-            for (int l = 0; l < N; ++l) {                        // Joseph update with R = 1: P -= beta g g^T
-                const double w = beta * g[l];
-#pragma unroll
-                for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
-            }
-#else
-            pb[0] = fma(-beta, g[0], pb[0]);
-#endif
 #pragma unroll
             for (int e = 0; e < NP; ++e) {
                 if (r < PV) p[r < PV ? r : 0][e] = pb[e];
