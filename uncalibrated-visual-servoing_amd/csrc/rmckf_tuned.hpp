@@ -242,11 +242,7 @@ struct PlantLds {
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
 __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
-#ifdef UVS_L4_XLDS
-    constexpr bool XREG = false;
-#else
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
-#endif
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool SPLIT = (PLANT == UVS_PLANT_DH_PINHOLE) && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
@@ -278,12 +274,8 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
     double *pq = A.q_out.p ? A.q_out.at(trial, 0, grp * JG) : nullptr;
     double *pd = A.dq_out.p ? A.dq_out.at(trial, 0, grp * JG) : nullptr;
-#ifdef UVS_FIXED_OUTPUTS          // diagnostic: outputs of the bench configuration wired at compile time
-    constexpr bool on_noise = true, on_err = true, on_f = false, on_q = true, on_dq = false;
-#else
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
-#endif
 
     if constexpr (PLANT == UVS_PLANT_DH_PINHOLE) {
         if (lane < N) {
