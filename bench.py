@@ -178,8 +178,8 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 5], help='BASELINE.json config: 2 (headline), 3 (mixture + annealing, 262144 trials), 5 (16-feature / 7-DoF stress)')
     ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
     ap.add_argument('--trials', type=int, default=0, help='trials per GPU (default: the size BASELINE.json names for the config)')
