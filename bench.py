@@ -127,7 +127,7 @@ def cpu_baseline(q_starts, budget_trials_per_core=256):
 
 
 # ---------------------------------------------------------------------------------------------- main
-def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T, K, M, N, reps=4):
+def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T, K, M, N, reps=20):
     """Replay mode (SURVEY 8d kernel microbenchmark): the estimator (+ control law) over recorded feature / joint-delta streams,
     the I/O north_star prices: read f and dq, write X and err.  Synthetic consistent streams f_{k+1} = f_k + J dq_k dt + noise built on
     the device; reuses the closed-loop run's output buffers.  Reported next to, never as, the closed-loop `value`."""
