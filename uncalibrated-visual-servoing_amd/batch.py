@@ -12,9 +12,9 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import dist, engine, noise_device
-from .experiment import ExperimentStatus, Method
+from .experiment import ExperimentStatus, Method, bandwidth_log
 from .noise import NoiseProfiler, NoiseType, noise_batch
-from .plant import SyntheticPlant
+from .plant import SyntheticPlant, camera_pose
 
 REQUIRED = {'experiments': ('dt', 't_max', 'epoch', 'ibvs_gain', 'q_start', 'desired_f', 'visualization', 'change_q_start', 'seed'),
             'estimator': ('method', 'estimator_params'),
@@ -68,7 +68,14 @@ def plan_trials(cfg, cells=None, epoch=None):
         q0[:, 0] += 2 * (g0.random(T) - 1) * (np.pi / 18)           # main.py:133
         q0[:, 1] += 2 * (g1.random(T) - 1) * (np.pi / 9)            # main.py:134
     seed0 = nz['seed']
-    seeds = (seed0 + np.arange(T)) if seed0 is not None else np.full(T, -1)
+    if seed0 is not None:
+        seeds = seed0 + np.arange(T)                                # main.py:137-139: seed, seed + 1, ... over the whole sweep
+    else:
+        # seed: null is legal in the reference: main.py:138 skips the increment and NoiseProfiler(seed=None) falls back to
+        # default_rng() per generator (noise.py:61-70), i.e. every trial gets independent OS-entropy streams.  Draw one fresh
+        # 62-bit seed per trial (so that seed + 10 j and 2 seed + i stay below 2^64) and keep them in the plan / npz sink:
+        # the run is then reproducible after the fact, and no two trials share a noise realisation.
+        seeds = (np.random.SeedSequence().generate_state(T, np.uint64) >> np.uint64(2)).astype(np.int64)
     return TrialPlan(cell=np.repeat(np.arange(len(cells)), epoch), value=np.repeat(cells, epoch), seed=seeds, q_start=q0, cells=cells)
 
 
@@ -172,12 +179,13 @@ def write_results_csv(result, cfg, plant, path):
     noise = result.noise.cpu().numpy()
     status, k_done = result.status.cpu().numpy(), result.k_done.cpu().numpy()
     desired = np.asarray(cfg['experiments']['desired_f'], float)
+    method, p = Method[cfg['estimator']['method']], cfg['estimator']['estimator_params']
     header = not os.path.exists(path)
     for j in range(result.hi - result.lo):
         k = int(k_done[j])
         cam = np.zeros((k, 6))
         for i in range(k):
-            cam[i, :3] = plant.fkine_all(q[i, :, j])[-1][:3, 3]
+            cam[i] = camera_pose(plant.fkine_all(q[i, :, j])[-1])   # computePose (ur10_simulation.py:151-163)
         cols = {'experiment_id': result.lo + j, 'status': ExperimentStatus(int(status[j])), 'rho': result.plan.value[result.lo + j],
                 't': result.t[:k]}
         cols.update({f'q_{i + 1}': q[:k, i, j] for i in range(6)})
@@ -185,7 +193,8 @@ def write_results_csv(result, cfg, plant, path):
         cols.update({f'f_{i + 1}': f[:k, i, j] for i in range(8)})
         cols.update({f'desired_f_{i + 1}': np.full(k, desired[i]) for i in range(8)})
         cols.update({f'noise_{i + 1}': noise[:k, i, j] for i in range(8)})
-        cols['kernel_bw'] = np.full(k, -1.0)                        # -1 unless MCKF (experiment.py:330)
+        cols['kernel_bw'] = bandwidth_log(method, k, p.get('kernel_bw', 1.0), p.get('annealing', False), cfg['experiments']['dt'],
+                                          cfg['experiments']['t_max'])                      # -1 unless MCKF (experiment.py:330)
         pd.DataFrame(data=cols).to_csv(path, mode='a', index=False, header=header)
         header = False
 

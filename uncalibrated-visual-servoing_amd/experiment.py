@@ -16,7 +16,7 @@ from enum import Enum
 import numpy as np
 
 from . import engine
-from .plant import SyntheticRobot
+from .plant import SyntheticRobot, camera_pose
 from .utils import gaussianKernel  # noqa: F401  (re-exported like the reference module namespace)
 
 
@@ -46,6 +46,16 @@ def detect4Circles(image):
 _GPU_METHODS = (Method.KF, Method.MCKF, Method.IMCCKF, Method.GMCKF)
 
 
+def bandwidth_log(method, k, kernel_bw, annealing, t_s, t_max):
+    """kernel_bw_log of a k-row trial: the (annealed) bandwidth for MCKF, -1 for every other method -- GMCKF included
+    (experiment.py:330; the MCKF branch rebinds kernel_bw per step at :196-200, every other branch leaves the initial -1)."""
+    if method != Method.MCKF:
+        return np.full(k, -1.0)
+    k_max = int(t_max / t_s)                                         # experiment.py:120
+    steps = np.arange(k)
+    return (kernel_bw + 100 * (1 - steps / k_max)) if annealing else np.full(k, float(kernel_bw))
+
+
 class Experiment:
     def __init__(self, q_start: list, desired_f: list, noise_prof: object, t_s: float, t_max: float, ibvs_gain: float,
                  robot: object, method: Method, logger: object = None, **method_params) -> None:
@@ -73,12 +83,7 @@ class Experiment:
                                   getattr(self, 'fpi_threshold', 0.1), getattr(self, 'fpi_epoch_max', 1000))
 
     def _bandwidth_log(self, k):
-        """kernel_bw_log: the annealed bandwidth for MCKF, -1 for every other method (experiment.py:330)."""
-        if self.method != Method.MCKF:
-            return np.full(k, -1.0)
-        k_max = int(self.t_max / self.t_s)
-        steps = np.arange(k)
-        return (self.kernel_bw + 100 * (1 - steps / k_max)) if self.annealing else np.full(k, float(self.kernel_bw))
+        return bandwidth_log(self.method, k, getattr(self, 'kernel_bw', 1.0), getattr(self, 'annealing', False), self.t_s, self.t_max)
 
     def run(self) -> list:
         if self.method not in _GPU_METHODS:
@@ -115,7 +120,7 @@ class Experiment:
         f_log = out['f'][:k, :, 0].cpu().numpy()
         cam = np.zeros((k, 6))
         for i in range(k):
-            cam[i, :3] = robot.plant.fkine_all(q_log[i])[-1][:3, 3]
+            cam[i] = camera_pose(robot.plant.fkine_all(q_log[i])[-1])          # computePose (ur10_simulation.py:151-163)
         if status == ExperimentStatus.FAIL:
             self.logger.error('Experiment failed')
         else:

@@ -21,6 +21,20 @@ def focal_length(resolution=RESOLUTION, fov_deg=FOV_DEG):
     return resolution / (2 * np.tan(0.5 * np.deg2rad(fov_deg)))            # experiment.py:97
 
 
+def camera_pose(T):
+    """[x, y, z, roll, pitch, yaw] of a homogeneous camera transform, as UR10Simulation.computePose returns it
+    (ur10_simulation.py:151-163): position, then the angles utils.quat2euler extracts from the simulator's scalar-first
+    quaternion -- R = Rz(yaw) Ry(pitch) Rx(roll), i.e. roll = atan2(R21, R22), pitch = asin(-R20), yaw = atan2(R10, R00)
+    (the reference's own commented-out matrix form, ur10_simulation.py:158-160)."""
+    T = np.asarray(T, float)
+    pose = np.empty(6)
+    pose[:3] = T[:3, 3]
+    pose[3] = np.arctan2(T[2, 1], T[2, 2])
+    pose[4] = np.arcsin(np.clip(-T[2, 0], -1.0, 1.0))
+    pose[5] = np.arctan2(T[1, 0], T[0, 0])
+    return pose
+
+
 @dataclass
 class SyntheticPlant:
     theta_offset: np.ndarray
@@ -208,7 +222,7 @@ class SyntheticRobot:
         return self.fkine(recalculate_fkine)[:3, 3]
 
     def computePose(self, recalculate_fkine=False):
-        return np.concatenate([self.fkine(True)[:3, 3], np.zeros(3)])
+        return camera_pose(self.fkine(True))
 
     def computeZ(self, n=1, recalculate_fkine=False):
         cam = self.getCameraPosition(recalculate_fkine)
