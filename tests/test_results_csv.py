@@ -1,0 +1,83 @@
+"""results.csv sink against the on-disk format of the reference's own main.py (main.py:152-196).
+
+tests/golden/results_{mckf_anneal,gmckf}.csv were written by the unmodified main.py (oracle/gen_golden_csv.py, build container):
+12 sweep cells x 1 trial x 10 rows.  The CPU test feeds the fixture's own per-step streams through `batch.write_results_csv` and
+requires the text of every pass-through column to be identical; the GPU test runs the same sweep on the HIP kernel and compares values."""
+import io
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+
+FIXTURES = ('results_mckf_anneal', 'results_gmckf')
+PASS_THROUGH = (['experiment_id', 'status', 'rho', 't'] + [f'q_{i}' for i in range(1, 7)] + [f'f_{i}' for i in range(1, 9)] +
+                [f'desired_f_{i}' for i in range(1, 9)] + [f'noise_{i}' for i in range(1, 9)] + ['kernel_bw'])
+
+
+def _load(name):
+    text = open(os.path.join(GOLDEN, name + '.csv'), encoding='utf-8').read()
+    cfg = json.load(open(os.path.join(GOLDEN, name + '.config.json')))
+    cfg.pop('_provenance', None)
+    return text, pd.read_csv(io.StringIO(text), float_precision='round_trip'), cfg
+
+
+def _columns_as_text(text, cols):
+    rows = [ln.split(',') for ln in text.strip().splitlines()]
+    idx = [rows[0].index(c) for c in cols]
+    return [[r[i] for i in idx] for r in rows]
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_csv_sink_reproduces_the_reference_file(name, tmp_path):
+    import torch
+    import uvs_amd
+    text, df, cfg = _load(name)
+    assert list(df.columns) == uvs_amd.batch.CSV_COLUMNS                   # header of the reference's own file
+    plan = uvs_amd.batch.plan_trials(cfg)
+    T, K = len(plan), 10
+    assert T == 12 and len(df) == T * K
+    stream = lambda prefix, n: torch.as_tensor(np.stack([df[df.experiment_id == j][[f'{prefix}_{i}' for i in range(1, n + 1)]].values for j in range(T)], axis=2))  # noqa: E731
+    res = SimpleNamespace(plan=plan, lo=0, hi=T, t=uvs_amd.engine.loop_clock(0.05, cfg['experiments']['t_max']),
+                          status=torch.zeros(T, dtype=torch.int32), k_done=torch.full((T,), K, dtype=torch.int32),
+                          streams={'q': stream('q', 6), 'f': stream('f', 8)}, noise=stream('noise', 8))
+    path = tmp_path / 'results.csv'
+    uvs_amd.batch.write_results_csv(res, cfg, uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']), str(path))
+    mine = open(path, encoding='utf-8').read()
+    assert mine.splitlines()[0] == text.splitlines()[0]
+    assert _columns_as_text(mine, PASS_THROUGH) == _columns_as_text(text, PASS_THROUGH)      # same text, not just close values
+    got = pd.read_csv(path, float_precision='round_trip')
+    cam = ['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw']
+    assert np.allclose(got[cam].values, df[cam].values, rtol=0, atol=1e-12)                 # computePose from our kinematics
+    # sweep bookkeeping of main.py: global trial index, swept value in `rho`, first jitter draws
+    assert list(df.groupby('experiment_id')['rho'].first()) == list(plan.value)
+    assert np.allclose(df[df.t == df.t.min()][['q_1', 'q_2']].values, plan.q_start[:, :2], rtol=0, atol=0)
+    bw = df['kernel_bw'].values.reshape(T, K)
+    if name == 'results_mckf_anneal':
+        assert np.array_equal(bw, np.tile(10 + 100 * (1 - np.arange(K) / 10), (T, 1)))     # annealed bandwidth (experiment.py:196-200, 330)
+    else:
+        assert np.all(bw == -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', FIXTURES)
+def test_gpu_sweep_writes_the_reference_file(name, tmp_path):
+    """The reference's sweep on the HIP kernel, written through the CSV sink, against the file the reference wrote."""
+    import uvs_amd
+    text, df, cfg = _load(name)
+    res = uvs_amd.batch.run_batch(cfg, want=('err', 'q', 'f'))
+    path = tmp_path / 'results.csv'
+    uvs_amd.batch.write_results_csv(res, cfg, uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']), str(path))
+    mine = open(path, encoding='utf-8').read()
+    exact = ['experiment_id', 'status', 'rho', 't'] + [f'desired_f_{i}' for i in range(1, 9)] + ['kernel_bw']
+    assert mine.splitlines()[0] == text.splitlines()[0] and _columns_as_text(mine, exact) == _columns_as_text(text, exact)
+    got = pd.read_csv(path, float_precision='round_trip')
+    assert len(got) == len(df)
+    for cols, tol in (([f'noise_{i}' for i in range(1, 9)], 1e-11), ([f'f_{i}' for i in range(1, 9)], 1e-8), ([f'q_{i}' for i in range(1, 7)], 1e-8),
+                      (['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw'], 1e-8)):
+        a, b = got[cols].values, df[cols].values
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), cols
