@@ -110,9 +110,17 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap);
  *   f_out    [T][K][m]   out  noisy features (f_log, :325)
  *   dq_out   [T][K][n]   out  commanded joint rate (:312)
  *   stats    [T][3]      out  ||ISE||_2, ||IAE||_2, ||ITAE||_2 over features (results/plot_errorbar.m:39-84)
- *   status   [T] int32   out  UVS_STATUS_* ; FAIL when X turns non-finite (pinv raises, :313-316)
+ *   status   [T] int32   out  UVS_STATUS_* ; FAIL when X turns non-finite (pinv raises, :313-316).  REQUIRED: between the two
+ *                             passes described below it also carries the marks of the trials to redo
  *   k_done   [T] int32   out  rows logged (k at exit, :345)
  *   x_final  [T][1][m*n], p_final [T][1][m*n*n] out  state after the last step (NULL to skip)
+ *
+ * numpy.linalg.pinv semantics (experiment.py:312: SVD, singular values <= 1e-15 * sigma_max dropped).  The kernels solve the control law
+ * by Householder least squares, which equals pinv(J) y for full column rank.  Every solve watches the spread of |R_cc|; a trial in which
+ * it reaches 2^34 (or a column vanishes) is marked and re-run from its first step by a second, careful kernel that the call enqueues
+ * right behind the first: its control law finishes the QR with a Jacobi SVD of the n x n factor and applies numpy's cutoff, i.e. it
+ * returns the truncated minimum-norm command the reference computes for a (numerically) rank-deficient Jacobian.  Healthy trials are not
+ * touched by the second pass; the marks never leave the library.
  */
 int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T,
                               uvs_view q_start, uvs_view noise, uvs_view x0,
@@ -127,7 +135,7 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
  *   dq       [T][K][n]    in   regressor of step k (previous command, :188); row 0 ignored (H = 0, :183)
  *   x0       [T][1][m*n]  in
  *   x_out    [T][K][m*n], err_out [T][K][m], kappa_out [T][K][m], dqcmd_out [T][K][n]  out (NULL to skip)
- *   status   [T] int32, k_done [T] int32  out
+ *   status   [T] int32, k_done [T] int32  out   (status is REQUIRED when dqcmd_out is requested: same two-pass scheme as the closed loop)
  */
 int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs_view dq, uvs_view x0,
                          uvs_view x_out, uvs_view err_out, uvs_view kappa_out, uvs_view dqcmd_out,

@@ -132,7 +132,7 @@ def run_reference(method, noise_type, noise_params, seed, q_start=Q_START, hold=
     return out, rec, params
 
 
-def save_closed(name, method, noise_type, noise_params, seed, x_stride=1, **kw):
+def save_closed(name, method, noise_type, noise_params, seed, x_stride=1, prefix='closed_', f_init=None, extra=None, **kw):
     out, rec, params = run_reference(method, noise_type, noise_params, seed, **kw)
     status, t, err, q, f, fd, cam, noise, bw = out
     k = len(t)
@@ -142,20 +142,21 @@ def save_closed(name, method, noise_type, noise_params, seed, x_stride=1, **kw):
     mask = np.kron(np.eye(8), np.ones((6, 6))) == 0
     off_block = max(float(np.abs(r['P'][mask]).max()) for r in rec)
     x_idx = np.unique(np.r_[np.arange(0, k, x_stride), np.arange(min(k, 12)), k - 1])
-    plant0 = RefPlant()
-    plant0.start(np.array(kw.get('q_start', Q_START), float))
-    f_init = plant0.features()                                        # f before the loop (experiment.py:90)
+    if f_init is None:
+        plant0 = RefPlant()
+        plant0.start(np.array(kw.get('q_start', Q_START), float))
+        f_init = plant0.features()                                    # f before the loop (experiment.py:90)
     dq_prev = np.stack([r['dq'].ravel() for r in rec])[:k]            # regressor used at step k (experiment.py:188)
     meta = dict(method=method.name, noise_type=noise_type.name, noise_params=noise_params, seed=seed,
                 hold=bool(kw.get('hold', False)), hold_cnt=int(kw.get('hold_cnt', 10)), params=params,
                 dt=DT, t_max=T_MAX, gain=GAIN, generator='oracle/gen_golden.py', reference='experiment.py Experiment.run()')
-    np.savez_compressed(os.path.join(OUT, f'closed_{name}.npz'),
+    np.savez_compressed(os.path.join(OUT, f'{prefix}{name}.npz'), **(extra or {}),
                         meta=json.dumps(meta), status=status.value, q_start=np.array(kw.get('q_start', Q_START), float), desired=DESIRED,
                         t=t, err=err, q=q, f=f, noise=noise, cam=cam, sigma_log=bw, f_init=f_init, dq_prev=dq_prev,
                         X=X[x_idx], X_steps=x_idx, P_steps=np.array(steps), P_blocks=P_blocks, P_offblock_max=off_block,
                         e=np.stack([r['e'].ravel() for r in rec])[:k] if 'e' in rec[0] else np.zeros(0),
                         sigma=np.array([float(r['kernel_bw']) for r in rec])[:k] if 'kernel_bw' in rec[0] else np.zeros(0))
-    print(f'closed_{name}: status={status.name} k={k} |err[-1]|={np.linalg.norm(err[-1]):.6g} offblock={off_block:g}')
+    print(f'{prefix}{name}: status={status.name} k={k} |err[-1]|={np.linalg.norm(err[-1]):.6g} offblock={off_block:g}')
     return out, rec
 
 

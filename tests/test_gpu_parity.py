@@ -155,8 +155,15 @@ def test_experiment_api_drop_in(uvs, name):
     status, t, err, q, f, fd, cam, noise, bw = ex.run()
     assert status == uvs.ExperimentStatus.SUCCESS and status.value == int(g['status'])
     assert np.array_equal(t, g['t']) and np.array_equal(noise, g['noise'])
-    for got, ref in ((err, g['err']), (q, g['q']), (f, g['f']), (cam, g['cam'])):
+    for got, ref in ((err, g['err']), (q, g['q']), (f, g['f']), (cam[:, :3], g['cam'][:, :3])):
         assert got.shape == ref.shape and rel_err(got, ref) <= 1e-8
+    # the generator's plant logged zero angles; computePose's roll / pitch / yaw (ur10_simulation.py:151-163) are checked against the
+    # oracle's kinematics in the reference's quat2euler convention
+    from oracle import plant_ref
+    for k in (0, 100, len(t) - 1):
+        R = plant_ref.fkine_all(g['q'][k])[5][:3, :3]
+        ref = [np.arctan2(R[2, 1], R[2, 2]), np.arcsin(-R[2, 0]), np.arctan2(R[1, 0], R[0, 0])]
+        assert cam.shape == (len(t), 6) and np.allclose(cam[k, 3:], ref, rtol=0, atol=1e-8)
     assert np.array_equal(fd, np.tile(g['desired'], (len(t), 1))) and np.array_equal(bw, g['sigma_log'])
 
 

@@ -1,0 +1,109 @@
+"""numpy.linalg.pinv semantics of the control law (experiment.py:312: SVD, rcond = 1e-15) on the GPU path.
+
+Fixtures `rankdef_*` come from the unmodified reference started on rank-deficient X0 (oracle/gen_golden_rankdef.py).  The kernels'
+least squares flags such trials (|R_cc| spread) and the library's careful second pass redoes them with the SVD of the triangular factor;
+what is tested: the result equals the reference's truncated minimum-norm command on every lane variant, healthy trials in the same batch
+are not touched by the second pass, and no internal status leaks out."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RANKDEF = golden_names('rankdef_')
+HORIZON = {'rankdef_gmckf_dup_col': 40}          # identical columns separate by rounding; past pinv's cutoff the command is noise-driven
+LANES_86 = (0, 1, 2, 4, -1, -2, -4, 8)
+
+
+@pytest.fixture(scope='module')
+def uvs():
+    import uvs_amd
+    uvs_amd.lib()
+    return uvs_amd
+
+
+def _cuda(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), device='cuda')
+
+
+def _fp(uvs, g, lanes=0, steps=None):
+    meta, p = g['meta'], g['meta']['params']
+    return uvs.engine.make_params(8, 6, meta['method'], p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'],
+                                  g['desired'], False, lanes, steps)
+
+
+@pytest.mark.parametrize('lanes', LANES_86)
+@pytest.mark.parametrize('name', RANKDEF)
+def test_replay_matches_reference_on_rank_deficient_jacobians(uvs, name, lanes):
+    g = load_golden(name)
+    K = len(g['t'])
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    T = 3
+    out = uvs.engine.replay(_fp(uvs, g, lanes), _cuda(np.repeat(f_seq[:, :, None], T, axis=2)), _cuda(np.repeat(g['dq_prev'][:, :, None], T, axis=2)),
+                            _cuda(np.tile(g['X'][0], (T, 1))))
+    h = HORIZON.get(name, K)
+    X, cmd = out['x'].cpu().numpy(), out['dqcmd'].cpu().numpy()
+    assert np.array_equal(cmd[:, :, 0], cmd[:, :, 2], equal_nan=True)
+    assert rel_err(X[g['X_steps'], :, 0][:h], g['X'][:h]) <= 1e-10
+    assert rel_err(cmd[:h - 1, :, 0], g['dq_prev'][1:h]) <= 1e-8                    # pinv's truncated minimum-norm command
+    assert set(out['status'].cpu().numpy().tolist()) == {0} and int(out['k_done'][0]) == K
+
+
+@pytest.mark.parametrize('lanes', (0, -2, 4))
+@pytest.mark.parametrize('name', [n for n in RANKDEF if n not in HORIZON])
+def test_closed_loop_matches_reference_on_rank_deficient_jacobians(uvs, name, lanes):
+    g = load_golden(name)
+    K = len(g['t'])
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    out = uvs.engine.closed_loop(_fp(uvs, g, lanes), plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:, :, None]),
+                                 _cuda(g['X'][0][None]), want=('x', 'err', 'q', 'dq'))
+    assert int(out['status'][0]) == 0 and int(out['k_done'][0]) == K
+    err, q, X = (out[k].cpu().numpy()[:, :, 0] for k in ('err', 'q', 'x'))
+    assert rel_err(err, g['err']) <= 1e-7 and rel_err(q, g['q']) <= 1e-7 and rel_err(X[g['X_steps']], g['X']) <= 1e-7
+    from oracle.rmckf_dense import trial_stats
+    assert rel_err(out['stats'].cpu().numpy()[0], trial_stats(g['err'], g['t'])) <= 1e-7
+
+
+def test_second_pass_leaves_healthy_trials_alone(uvs):
+    """A batch mixing healthy and rank-deficient X0: healthy trials come out bit-identical to a batch without the sick ones."""
+    g, h = load_golden('rankdef_gmckf_rank4_product'), load_golden('closed_gmckf_a1p5')
+    K, T = 120, 160
+    sick = [3, 40]
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    rng = np.random.default_rng(5)
+    x0 = np.tile(h['X'][0], (T, 1)) * (1 + 0.02 * rng.standard_normal((T, 1)))
+    noise = rng.standard_t(3, size=(K, 8, T))
+    for t in sick:
+        x0[t] = g['X'][0]
+        noise[:, :, t] = g['noise'][:K]
+    q0 = np.tile(g['q_start'], (T, 1))
+    fp = _fp(uvs, g, 0, steps=K)
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise), _cuda(x0), want=('x', 'err', 'q'))
+    keep = [t for t in range(T) if t not in sick]
+    ref = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0[keep]), _cuda(noise[:, :, keep]), _cuda(x0[keep]), want=('x', 'err', 'q'))
+    # not bit-identical by design: a sick trial's first-pass joints run away, and one out-of-range angle switches its whole wavefront
+    # from the bounded sincos to the library routine (rmckf_tuned.hpp), which rounds the neighbours' last bit differently
+    for key in ('x', 'err', 'q'):
+        assert rel_err(out[key].cpu().numpy()[:, :, keep], ref[key].cpu().numpy()) <= 1e-11
+    assert rel_err(out['stats'].cpu().numpy()[keep], ref['stats'].cpu().numpy()) <= 1e-11
+    far = [t for t in keep if t >= 64]                          # wavefronts (32 trials each) without a sick trial: bit-identical
+    assert np.array_equal(out['err'].cpu().numpy()[:, :, far], ref['err'].cpu().numpy()[:, :, [keep.index(t) for t in far]])
+    assert not out['status'].cpu().numpy().any() and not ref['status'].cpu().numpy().any()
+    for t in sick:
+        assert rel_err(out['err'].cpu().numpy()[:, :, t], g['err'][:K]) <= 1e-7 and rel_err(out['q'].cpu().numpy()[:, :, t], g['q'][:K]) <= 1e-7
+
+
+def test_single_step_bank_uses_pinv_semantics(uvs):
+    """External-robot route (FilterBank / uvs_rmckf_step_f64): the careful solve is inline."""
+    g = load_golden('rankdef_gmckf_zero_and_scaled_col')
+    fp = _fp(uvs, g, 0, steps=0)
+    bank = uvs.engine.FilterBank(fp, 1, g['X'][0])
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    for k in range(25):
+        dq, err, kap, st = bank.step(_cuda(f_seq[k + 1][None]), _cuda(f_seq[k][None]), _cuda(g['dq_prev'][k][None]), k)
+        assert int(st[0]) == 0
+        if k + 1 < 25:
+            ref = g['dq_prev'][k + 1]
+            assert np.abs(dq[0].cpu().numpy() - ref).max() <= 1e-8 * max(1e-3, np.abs(ref).max())

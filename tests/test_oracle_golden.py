@@ -139,3 +139,32 @@ def test_block_replay_matches_reference_scripts(name):
     assert float(g['P_offblock_max']) == 0.0
     if meta['method'] == 'MCKF':
         assert np.array_equal(out['fpi_iterations'], g['epochs']) and g['epochs'].max() >= 2
+
+
+# ---------------------------------------------------------------------------------------------- rank-deficient Jacobians (pinv semantics)
+RANKDEF = golden_names('rankdef_')
+# identical columns: the deficiency decays as rounding separates them; once sigma_6 crosses pinv's 1e-15 cutoff the command is noise-driven
+RANKDEF_HORIZON = {'rankdef_gmckf_dup_col': 40}
+
+
+def test_rankdef_fixture_inventory():
+    assert RANKDEF == ['rankdef_gmckf_dup_col', 'rankdef_gmckf_rank1', 'rankdef_gmckf_rank4_product', 'rankdef_gmckf_zero_and_scaled_col',
+                       'rankdef_kf_rank4_product']
+    for name in RANKDEF:
+        g = load_golden(name)
+        s = np.linalg.svd(g['x0'].reshape(8, 6), compute_uv=False)
+        assert s[-1] <= 1e-15 * s[0] and not g['meta']['params']['initial_guess']      # pinv truncates from the first step on
+
+
+@pytest.mark.parametrize('name', RANKDEF)
+def test_block_replay_matches_reference_on_rank_deficient_jacobians(name):
+    """The reference run from a rank-deficient X0 (oracle/gen_golden_rankdef.py): every command is pinv's truncated minimum-norm solution."""
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    assert np.array_equal(g['X'][0], g['x0']) and not np.any(g['f_init'])
+    out = rmckf_block.run_replay(f_seq, g['dq_prev'], g['X'][0], g['desired'], meta['gain'], method=meta['method'],
+                                 kernel_bw=p['kernel_bw'], annealing=p['annealing'], k_max=int(meta['t_max'] / meta['dt']))
+    h = RANKDEF_HORIZON.get(name, len(g['t']))
+    assert rel_err(out['X'][g['X_steps']][:h], g['X'][:h]) <= 1e-11
+    assert rel_err(out['dq_cmd'][:h - 1], g['dq_prev'][1:h]) <= 1e-8

@@ -19,6 +19,14 @@
 #define UVS_TUNED_SHAPES_B(X) X(8, 6, 1) X(8, 6, 4)
 #endif
 #define UVS_SHAPES(X) UVS_SHAPES_A(X) UVS_SHAPES_B(X)
+// one careful (numpy-pinv) instantiation of the generic closed-loop / replay kernels per shape: the second pass over suspect trials
+#ifdef UVS_QUICK
+#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 2)
+#define UVS_CAREFUL_SHAPES_B(X)
+#else
+#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 2) X(2, 6, 1)
+#define UVS_CAREFUL_SHAPES_B(X) X(6, 6, 2) X(32, 7, 16)
+#endif
 #define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6) X(6, 6)
 
 namespace uvs_launch {
@@ -34,6 +42,11 @@ bool closed_generic_b(int m, int n, int L, int method, int64_t T, hipStream_t s,
 bool replay_generic_a(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool replay_generic_b(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool step_generic(int m, int n, int L, int64_t T, hipStream_t s, const uvs::StepArgs &A);
+// careful second pass (rmckf_generic.hpp, CAREFUL = true): re-runs the trials whose status the first pass left at UVS_STATUS_SUSPECT
+bool closed_careful_a(int m, int n, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+bool closed_careful_b(int m, int n, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+bool replay_careful_a(int m, int n, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+bool replay_careful_b(int m, int n, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 // tuned replay (rmckf_replay_tuned.hpp): two lanes per filter with the control law, four lanes per filter for the estimator alone
 bool replay_tuned(int m, int n, int method, bool xo, bool cmd, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool replay_rows(int m, int n, int method, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);

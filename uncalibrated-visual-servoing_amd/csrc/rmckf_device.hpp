@@ -389,14 +389,105 @@ struct Rows {
     }
 };
 
+// ---------------------------------------------------------------- numpy.linalg.pinv semantics for ill-conditioned Jacobians
+// The reference solves the control law with numpy's pinv (experiment.py:312): SVD, singular values <= 1e-15 * sigma_max dropped.
+// For full-rank J that equals the Householder least-squares solution the kernels compute; for (numerically) rank-deficient J it is
+// the minimum-norm solution, which an unpivoted QR does not give.  Split of work:
+//   * every least-squares solve watches the spread of |R_cc| (all kernels, a handful of integer instructions): a spread of 2^34 or
+//     more -- or an exactly zero column next to non-zero ones -- marks the trial UVS_STATUS_SUSPECT;
+//   * suspect trials are re-run from their first step by the `careful` instantiation of the generic kernels, launched right behind
+//     the main kernel by the C ABI, whose control law finishes the same QR with a one-sided Jacobi SVD of the n x n factor R
+//     (pinv(J) y = pinv(R) Q^T y, same singular values as J) and applies numpy's cutoff.  The hot kernels stay free of that code.
+constexpr int UVS_STATUS_SUSPECT = 2;            // internal: never visible after an entry point returns
+constexpr unsigned kSuspectSpread = 68u << 20;   // exponent-field distance (high dword of a double) of R_cc^2: |R_cc| spread 2^34 ~ 1.7e10
+constexpr double kPinvRcond = 1e-15;             // numpy.linalg.pinv default (rcond=1e-15)
+
+// Running exponent range of the non-negative doubles R_cc^2 (their high dwords order like the values; a zero column gives 0).
+struct Spread {
+    unsigned lo = 0xffffffffu, hi = 0u;
+    UVS_DEV void add(double n2) {
+        const unsigned e = (unsigned)__double2hiint(n2);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+    }
+    UVS_DEV bool suspect() const { return hi - lo >= kSuspectSpread; }
+};
+
+// sol = pinv(Rm) c for a small square matrix through a one-sided Jacobi (Hestenes) SVD: columns of A = Rm are rotated until
+// mutually orthogonal, A = U diag(sigma), V accumulates the rotations, Rm = U diag(sigma) V^T.  numpy's cutoff: components with
+// sigma_j <= 1e-15 * sigma_max are dropped.  Only the careful kernels instantiate this (rare path; clarity over speed).
+template <int N>
+UVS_DEV void svd_solve(double (&A)[N][N], const double (&c)[N], double (&sol)[N]) {
+    double V[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    alpha = fma(A[i][p], A[i][p], alpha);
+                    beta = fma(A[i][q], A[i][q], beta);
+                    gamma = fma(A[i][p], A[i][q], gamma);
+                }
+                if (fabs(gamma) > 2.3e-16 * sqrt(alpha * beta) && gamma != 0.0) {
+                    rotated = true;
+                    const double zeta = (beta - alpha) / (2.0 * gamma);
+                    const double t = (fabs(zeta) > 1e150) ? 0.5 / zeta : copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+                    const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const double ap = A[i][p], aq = A[i][q];
+                        A[i][p] = cs * ap - sn * aq;
+                        A[i][q] = sn * ap + cs * aq;
+                        const double vp = V[i][p], vq = V[i][q];
+                        V[i][p] = cs * vp - sn * vq;
+                        V[i][q] = sn * vp + cs * vq;
+                    }
+                }
+            }
+        }
+        if (!__any(rotated)) break;
+    }
+    double s2[N], proj[N], s2max = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { a = fma(A[i][j], A[i][j], a); b = fma(A[i][j], c[i], b); }
+        s2[j] = a;
+        proj[j] = b;                                              // sigma_j * (u_j . c)
+        s2max = a > s2max ? a : s2max;
+    }
+    const double cut = kPinvRcond * sqrt(s2max);
+#pragma unroll
+    for (int i = 0; i < N; ++i) sol[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool large = sqrt(s2[j]) > cut;                     // numpy: s > rcond * max(s)
+        const double w = large ? proj[j] / s2[j] : 0.0;           // (u_j . c) / sigma_j
+#pragma unroll
+        for (int i = 0; i < N; ++i) sol[i] = fma(V[i][j], w, sol[i]);
+    }
+}
+
 // ---------------------------------------------------------------- control law: dq = -gain * pinv(J) y
 // Overdetermined / square case (M >= N): Householder QR of [J | y] distributed over the L lanes of the
 // group (each lane holds R rows), then back substitution.  Equals numpy's pinv(J) @ y (experiment.py:312)
 // for full-column-rank J; exactly-zero columns give a zero component (pinv(0) = 0).
-template <int M, int N, int L>
-UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
+template <int M, int N, int L, bool CAREFUL = false>
+UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
     constexpr int R = M / L;
     double diag[N];
+    double rcc[CAREFUL ? N : 1];                                 // R_cc, kept only for the careful finish
+    Spread spread;
 #pragma unroll
     for (int c = 0; c < N; ++c) {
         const int owner = c / R, prow = c % R;                    // lane / local row holding global row c
@@ -410,8 +501,10 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
         const double piv = group_pick<L>(a[prow][c], sub, owner);
         const double n2 = fma(piv, piv, sig);
         double nrm, rn;
-        fast_sqrt_rsqrt_1(n2, nrm, rn);                           // |R_cc| and its reciprocal
-        const double alpha = (piv >= 0.0) ? -nrm : nrm;
+        fast_sqrt_rsqrt_1(n2 > 0.0 ? n2 : 1.0, nrm, rn);          // |R_cc| and its reciprocal (a zero column must not breed NaNs)
+        spread.add(n2);
+        const double alpha = (n2 > 0.0) ? ((piv >= 0.0) ? -nrm : nrm) : 0.0;
+        if constexpr (CAREFUL) rcc[c] = alpha;
         const double vp = piv - alpha;                            // pivot entry of the Householder vector
         const double denom = n2;                                  // zero column <=> nothing to eliminate
         const double tau = (denom > 0.0) ? rn * fast_rcp_1(fabs(vp)) : 0.0;   // 2 / (v.v) = 1 / (nrm (nrm + |piv|))
@@ -435,6 +528,27 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
         }
         diag[c] = (denom > 0.0) ? ((piv >= 0.0) ? -rn : rn) : 0.0;  // 1 / R_cc (0 marks a zero column)
     }
+    const bool suspect = spread.suspect();
+    if constexpr (CAREFUL) {
+        // pinv(J) y = pinv(R) (Q^T y)[0:N]: gather the triangular factor and the transformed right-hand side on every lane of the group
+        // (the test is on replicated values, so the lanes of a group agree) and finish with the SVD
+        if (__any(suspect)) {
+            double Rm[N][N], cv[N], ss[N];
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const int owner = c / R, prow = c % R;
+#pragma unroll
+                for (int j = 0; j < N; ++j) Rm[c][j] = (j < c) ? 0.0 : (j == c ? rcc[c] : group_pick<L>(a[prow][j], sub, owner));
+                cv[c] = group_pick<L>(a[prow][N], sub, owner);
+            }
+            svd_solve<N>(Rm, cv, ss);
+            if (suspect) {
+#pragma unroll
+                for (int c = 0; c < N; ++c) sol[c] = ss[c];
+                return true;
+            }
+        }
+    }
 #pragma unroll
     for (int c = N - 1; c >= 0; --c) {
         const int owner = c / R, prow = c % R;
@@ -444,14 +558,16 @@ UVS_DEV void lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
         rhs = group_pick<L>(rhs, sub, owner);
         sol[c] = rhs * diag[c];
     }
+    return suspect;
 }
 
 // Underdetermined case (M < N, e.g. one feature: 2 x 6): minimum-norm solution through the QR of J^T.
 // Only instantiated with L == 1 (the whole J in one lane).
-template <int M, int N>
-UVS_DEV void lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&sol)[N]) {
+template <int M, int N, bool CAREFUL = false>
+UVS_DEV bool lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&sol)[N]) {
     double b[N][M];                                               // J^T, overwritten by R (upper) and v (lower)
     double vp[M], tau[M], diag[M];
+    Spread spread;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -468,6 +584,7 @@ UVS_DEV void lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&
         vp[c] = piv - alpha;
         tau[c] = (denom > 0.0) ? 1.0 / denom : 0.0;
         diag[c] = (denom > 0.0) ? alpha : piv;
+        spread.add(diag[c] * diag[c]);
 #pragma unroll
         for (int j = c + 1; j < M; ++j) {
             double d = vp[c] * b[c][j];
@@ -483,12 +600,32 @@ UVS_DEV void lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&
     double w[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) w[j] = 0.0;
+    const bool suspect = spread.suspect();
+    bool solved = false;
+    if constexpr (CAREFUL) {
+        // J = [R^T 0] Q^T, so pinv(J) y = Q [pinv(R^T) y; 0]: the m x m factor goes through the SVD with numpy's cutoff
+        if (__any(suspect)) {
+            double Rt[M][M], ws[M];
 #pragma unroll
-    for (int c = 0; c < M; ++c) {
-        double rhs = y[c];
+            for (int c = 0; c < M; ++c)
 #pragma unroll
-        for (int j = 0; j < c; ++j) rhs = fma(-b[j][c], w[j], rhs);
-        w[c] = (diag[c] != 0.0) ? rhs / diag[c] : 0.0;
+                for (int j = 0; j < M; ++j) Rt[c][j] = (j > c) ? 0.0 : (j == c ? diag[c] : b[j][c]);
+            svd_solve<M>(Rt, y, ws);
+            if (suspect) {
+#pragma unroll
+                for (int c = 0; c < M; ++c) w[c] = ws[c];
+                solved = true;
+            }
+        }
+    }
+    if (!solved) {
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+            double rhs = y[c];
+#pragma unroll
+            for (int j = 0; j < c; ++j) rhs = fma(-b[j][c], w[j], rhs);
+            w[c] = (diag[c] != 0.0) ? rhs / diag[c] : 0.0;
+        }
     }
 #pragma unroll
     for (int c = M - 1; c >= 0; --c) {
@@ -502,14 +639,17 @@ UVS_DEV void lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) sol[j] = w[j];
+    return suspect;
 }
 
 // dq = -gain * pinv(X.reshape(m, n)) @ (kappa o err)   (experiment.py:300-312); result replicated in the group
-template <int M, int N, int L>
-UVS_DEV void control_law(const Rows<M, N, L> &st, const double (&kap)[M / L], const double (&err)[M / L], double gain, int sub,
+// Returns true when the solve looked rank-deficient (see "numpy.linalg.pinv semantics" above); with CAREFUL the result is pinv's then.
+template <int M, int N, int L, bool CAREFUL = false>
+UVS_DEV bool control_law(const Rows<M, N, L> &st, const double (&kap)[M / L], const double (&err)[M / L], double gain, int sub,
                          double (&dq)[N]) {
     constexpr int R = M / L;
     double sol[N];
+    bool suspect;
     if constexpr (M >= N) {
         double a[R][N + 1];
 #pragma unroll
@@ -518,16 +658,17 @@ UVS_DEV void control_law(const Rows<M, N, L> &st, const double (&kap)[M / L], co
             for (int j = 0; j < N; ++j) a[r][j] = st.x[r][j];
             a[r][N] = kap[r] * err[r];
         }
-        lstsq_tall<M, N, L>(a, sub, sol);
+        suspect = lstsq_tall<M, N, L, CAREFUL>(a, sub, sol);
     } else {
         static_assert(M >= N || L == 1, "wide Jacobians are handled one filter per lane");
         double y[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) y[r] = kap[r] * err[r];
-        lstsq_wide<M, N>(st.x, y, sol);
+        suspect = lstsq_wide<M, N, CAREFUL>(st.x, y, sol);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) dq[j] = -gain * sol[j];
+    return suspect;
 }
 
 // ---------------------------------------------------------------- plant

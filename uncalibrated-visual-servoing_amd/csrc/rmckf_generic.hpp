@@ -27,7 +27,10 @@ UVS_DEV void store_final(const Rows<M, N, L> &st, const View &xf, const View &pf
 }
 
 // ------------------------------------------------------------------------------------------------ closed loop
-template <int M, int N, int L, int METHOD_T>
+// CAREFUL = true is the second pass behind any closed-loop kernel: it re-runs, from their first step, exactly the trials the first pass
+// marked UVS_STATUS_SUSPECT (a numerically rank-deficient Jacobian showed up in the control law) with numpy's pinv semantics, and
+// overwrites their outputs; wavefronts without such a trial exit at once.
+template <int M, int N, int L, int METHOD_T, bool CAREFUL = false>
 __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
     constexpr int R = M / L;
     const long long gl = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -37,6 +40,11 @@ __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
     if (!valid) trial = A.T - 1;                    // padding lanes shadow the last trial so group shuffles stay uniform
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
+    bool mine = true, flagged = false;
+    if constexpr (CAREFUL) {
+        mine = A.status[trial] == UVS_STATUS_SUSPECT;
+        if (!__any(mine)) return;
+    }
 
     double q[N], dq[N];
 #pragma unroll
@@ -90,9 +98,10 @@ __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
             k_done = k;
         }
         if (!__any(alive)) break;
-        control_law<M, N, L>(st, kap, err, fp.gain, sub, dq);
+        const bool suspect = control_law<M, N, L, CAREFUL>(st, kap, err, fp.gain, sub, dq);
+        flagged |= alive && suspect;
 
-        if (alive && valid) {
+        if (alive && valid && mine) {
             if (A.x_out.on()) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -132,18 +141,18 @@ __global__ __launch_bounds__(64) void closed_loop_kernel(const ClosedArgs A) {
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) s2[i] = sqrt(group_sum<L>(s2[i]));
-    if (valid) {
+    if (valid && mine) {
         store_final<M, N, L>(st, A.x_final, A.p_final, trial, sub);
         if (sub == 0) {
             if (A.stats) { A.stats[3 * trial] = s2[0]; A.stats[3 * trial + 1] = s2[1]; A.stats[3 * trial + 2] = s2[2]; }
-            if (A.status) A.status[trial] = status;
+            if (A.status) A.status[trial] = (!CAREFUL && flagged) ? UVS_STATUS_SUSPECT : status;
             if (A.k_done) A.k_done[trial] = k_done;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ replay
-template <int M, int N, int L, int METHOD_T>
+template <int M, int N, int L, int METHOD_T, bool CAREFUL = false>
 __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
     constexpr int R = M / L;
     const long long gl = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -153,6 +162,11 @@ __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
     if (!valid) trial = A.T - 1;
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
+    bool mine = true, flagged = false;
+    if constexpr (CAREFUL) {                        // second pass: only the trials the first pass marked suspect (see closed_loop_kernel)
+        mine = A.status[trial] == UVS_STATUS_SUSPECT;
+        if (!__any(mine)) return;
+    }
 
     Rows<M, N, L> st;
     st.init_cov();
@@ -184,8 +198,9 @@ __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
             k_done = k;
         }
         if (!__any(alive)) break;
-        control_law<M, N, L>(st, kap, err, fp.gain, sub, cmd);
-        if (alive && valid) {
+        const bool suspect = control_law<M, N, L, CAREFUL>(st, kap, err, fp.gain, sub, cmd);
+        flagged |= alive && suspect && A.dqcmd_out.on();        // the careful pass only follows when the command is an output
+        if (alive && valid && mine) {
             if (A.x_out.on()) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -203,10 +218,10 @@ __global__ __launch_bounds__(64) void replay_kernel(const ReplayArgs A) {
             }
         }
     }
-    if (valid) {
+    if (valid && mine) {
         store_final<M, N, L>(st, A.x_final, A.p_final, trial, sub);
         if (sub == 0) {
-            if (A.status) A.status[trial] = status;
+            if (A.status) A.status[trial] = (!CAREFUL && flagged) ? UVS_STATUS_SUSPECT : status;
             if (A.k_done) A.k_done[trial] = k_done;
         }
     }
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs A) {
     }
     st.template update<METHOD_T>(fp, z, h, bandwidth(fp, A.k), kap);
     const int bad = st.any_nonfinite();
-    control_law<M, N, L>(st, kap, err, fp.gain, sub, cmd);
+    control_law<M, N, L, true>(st, kap, err, fp.gain, sub, cmd);   // one step, latency-bound: numpy's pinv semantics inline
     if (!valid) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
 
     int status = UVS_STATUS_SUCCESS, k_done = K;
-    bool alive = true;
+    bool alive = true, flagged = false;                          // flagged: rank-deficient Jacobian seen -> careful second pass
     for (int k = 0; k < K; ++k) {
         double f[R], dq[N];
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
                 panel[r][N] = kap[r] * err[r];
             }
             double sol[N];
-            lstsq_tall_tuned<M, N, L>(panel, sub, sol);
+            flagged |= alive && lstsq_tall_tuned<M, N, L>(panel, sub, sol);
             if (pc) {                                            // each lane of the pair logs half of the command
                 double *po = pc;
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
 
     if (!valid) return;
     if (sub == 0) {
-        if (A.status) A.status[trial] = status;
+        if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
         if (A.k_done) A.k_done[trial] = k_done;
     }
     if (A.x_final.on()) {

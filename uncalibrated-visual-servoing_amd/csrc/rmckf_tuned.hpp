@@ -171,10 +171,13 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 // In column c the local row m = c / L is the pivot row on lane c % L, an ordinary "below" row on lanes > c % L and already
 // finished on lanes < c % L; rows r > m are below the pivot on every lane -- so all lanes run the same unrolled code and only
 // the treatment of row m is selected per lane.
+// Returns true when the |R_cc| spread marks the Jacobian as numerically rank-deficient (rmckf_device.hpp, "numpy.linalg.pinv
+// semantics"): the caller flags the trial and the careful second pass redoes it; the solution computed here is then discarded.
 template <int M, int N, int L>
-UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
+UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
     constexpr int R = M / L;
     double rdiag[N];
+    Spread spread;
 #pragma unroll
     for (int c = 0; c < N; ++c) {
         const int m = c / L, owner = c % L;
@@ -186,6 +189,7 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         sig = pair_sum<L>(sig);
         const double piv = pair_from_dyn<L>(a[m][c], owner);
         const double n2 = fma(piv, piv, sig);
+        spread.add(n2);
         double nrm, rn;
         fast_sqrt_rsqrt_1(n2, nrm, rn);                                 // |R_cc| and its reciprocal
         const bool zero = !(n2 > 0.0);
@@ -216,6 +220,7 @@ UVS_DEV void lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         rhs = pair_from_dyn<L>(rhs, owner);
         sol[c] = rhs * rdiag[c];
     }
+    return spread.suspect();
 }
 
 // Plant constants are broadcast from LDS (one ds_read per pair of doubles) instead of sitting in ~90 SGPRs that the register
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 
     double t = fp.dt;
     int status = UVS_STATUS_SUCCESS, k_done = K;
-    bool alive = true;
+    bool alive = true, flagged = false;                          // flagged: a rank-deficient Jacobian was seen -> careful second pass
 #ifdef UVS_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
             for (int j = 0; j < N; ++j) sol[j] = pair_sum<L>(panel[j % R][j] * 1e-4 + panel[(j + 1) % R][N] * 1e-3);
 #else
-            lstsq_tall_tuned<M, N, L>(panel, sub, sol);
+            flagged |= alive && lstsq_tall_tuned<M, N, L>(panel, sub, sol);
 #endif
 #pragma unroll
             for (int j = 0; j < N; ++j) dq[j] = -fp.gain * sol[j];
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
             for (int c = 0; c < 3; ++c) A.stats[3 * trial + c] = sqrt(s2[c]);
         }
-        if (A.status) A.status[trial] = status;
+        if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
         if (A.k_done) A.k_done[trial] = k_done;
     }
     if (A.x_final.on()) {

@@ -87,6 +87,7 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
         return fail(UVS_ERR_ARG, "%s", "unknown plant kind");
     }
     if (!q_start.base) return fail(UVS_ERR_ARG, "%s", "q_start view is NULL");
+    if (!status) return fail(UVS_ERR_ARG, "%s", "status is required (it also carries the suspect marks between the two passes)");
     if (!fp->initial_guess && !x0.base) return fail(UVS_ERR_ARG, "%s", "x0 view is required when initial_guess == 0");
     uvs::ClosedArgs A;
     A.fp = *fp;
@@ -106,7 +107,12 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     if (tuned_ok) launched = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
-    return check_launch("closed_loop_kernel");
+    if (int rc = check_launch("closed_loop_kernel")) return rc;
+    // second pass: trials in which the control law met a numerically rank-deficient Jacobian (status left at UVS_STATUS_SUSPECT) are
+    // re-run with numpy's pinv semantics (experiment.py:312); wavefronts without such a trial exit at once
+    if (!(closed_careful_a(fp->m, fp->n, T, s, A) || closed_careful_b(fp->m, fp->n, T, s, A)))
+        return fail(UVS_ERR_SHAPE, "%s", "(m, n) has no careful closed-loop instantiation in libuvs_rmckf");
+    return check_launch("closed_loop_kernel (careful pass)");
 }
 
 int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs_view dq, uvs_view x0, uvs_view x_out,
@@ -115,6 +121,7 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     int L = 0;
     if (int rc = check_params(fp, T, &L)) return rc;
     if (!f.base || !dq.base || !x0.base) return fail(UVS_ERR_ARG, "%s", "f, dq and x0 views are required");
+    if (dqcmd_out.base && !status) return fail(UVS_ERR_ARG, "%s", "status is required when the commanded dq is requested (it carries the suspect marks between the two passes)");
     uvs::ReplayArgs A;
     A.fp = *fp;
     A.T = T;
@@ -134,7 +141,13 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     if (!launched && tuned_ok) launched = replay_tuned(fp->m, fp->n, fp->method, x_out.base != nullptr, dqcmd_out.base != nullptr, T, s, A);
     if (!launched) launched = replay_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || replay_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
-    return check_launch("replay_kernel");
+    if (int rc = check_launch("replay_kernel")) return rc;
+    if (dqcmd_out.base) {                                          // the control law ran: careful second pass over the suspect trials
+        if (!(replay_careful_a(fp->m, fp->n, T, s, A) || replay_careful_b(fp->m, fp->n, T, s, A)))
+            return fail(UVS_ERR_SHAPE, "%s", "(m, n) has no careful replay instantiation in libuvs_rmckf");
+        return check_launch("replay_kernel (careful pass)");
+    }
+    return UVS_OK;
 }
 
 int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double *P, const double *f, const double *f_old,

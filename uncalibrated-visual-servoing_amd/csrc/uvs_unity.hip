@@ -12,5 +12,10 @@
 #undef UVS_TU_CLOSED
 #undef UVS_TU_REPLAY
 #include "tu_generic_b.hip"
+#include "tu_careful_a.hip"
+#undef UVS_TU_CAREFUL_SHAPES
+#undef UVS_TU_CLOSED_CAREFUL
+#undef UVS_TU_REPLAY_CAREFUL
+#include "tu_careful_b.hip"
 #include "tu_replay_tuned.hip"
 #include "tu_misc.hip"
