@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 CLOSED = golden_names('closed_')                                             # KF / MCKF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
 LANES_86 = (1, 2, 4, -1, -2, -4, 8)      # 1, 2, 4: tuned kernel (closed loop); negative: generic template with |L| lanes
+LANES_CLOSED = LANES_86 + (5,)           # 5: role-split closed-loop kernel (4 estimator lanes per filter + one control lane per trial)
 
 
 @pytest.fixture(scope='module')
@@ -106,7 +107,7 @@ def test_estimator_only_replay_fail_semantics(uvs):
 
 
 # ---------------------------------------------------------------------------------------------- closed loop
-@pytest.mark.parametrize('lanes', LANES_86)
+@pytest.mark.parametrize('lanes', LANES_CLOSED)
 @pytest.mark.parametrize('name', CLOSED)
 def test_closed_loop_matches_reference(uvs, name, lanes):
     """Whole trial in the kernel (plant + estimator + control) on the reference's noise: trajectories within 1e-8."""

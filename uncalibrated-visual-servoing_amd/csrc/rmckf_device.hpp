@@ -410,7 +410,8 @@ struct Spread {
         lo = e < lo ? e : lo;
         hi = e > hi ? e : hi;
     }
-    UVS_DEV bool suspect() const { return hi - lo >= kSuspectSpread; }
+    // lo == 0: a column vanished altogether (all of them when hi == 0 too, J = 0, where the plain solve would divide 0 by 0)
+    UVS_DEV bool suspect() const { return hi - lo >= kSuspectSpread || lo == 0u; }
 };
 
 // sol = pinv(Rm) c for a small square matrix through a one-sided Jacobi (Hestenes) SVD: columns of A = Rm are rotated until
