@@ -190,9 +190,11 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
-    ap.add_argument('--layout', default='kct', choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams')
+    ap.add_argument('--layout', default=None, choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams (default: trial-fastest kct; config 5: per-trial records ktc)')
     args = ap.parse_args()
 
+    if args.layout is None:
+        args.layout = 'ktc' if args.config == 5 else 'kct'    # 8 trials per wavefront at (32,7): only per-trial records give contiguous stores
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -271,7 +273,7 @@ def main():
         gq = np.random.default_rng(12345)
         q0 = torch.as_tensor(q_goal + gq.uniform(-0.15, 0.15, (len(plan), N))[lo:hi], device=dev)
         x0 = torch.as_tensor(np.tile((lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel(), (hi - lo, 1)), device=dev)
-        noise = uvs_amd.noise_device.generate(uvs_amd.NoiseType.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), plan.seed[lo:hi], M, K, device=dev)
+        noise = uvs_amd.noise_device.generate(uvs_amd.NoiseType.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), plan.seed[lo:hi], M, K, layout=args.layout, device=dev)
         fp = engine.make_params(M, N, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, desired, False, args.lanes)
         plant = lin.to_struct(dev)
     else:

@@ -290,9 +290,11 @@ def test_replay_other_shapes_match_block_oracle(uvs, m, n, lanes, method):
         assert rel_err(out['p_final'].cpu().numpy()[t].reshape(m, n, n), ref['P_final']) <= 1e-10
 
 
-@pytest.mark.parametrize('lanes', [8, 16, 32])
-def test_closed_loop_stress_plant(uvs, lanes):
-    """(m, n) = (32, 7) on the linear consistent plant (BASELINE config 5), closed loop, against the block oracle."""
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF'])
+@pytest.mark.parametrize('lanes', [0, 8, 16, 32, -8, -16])
+def test_closed_loop_stress_plant(uvs, lanes, method):
+    """(m, n) = (32, 7) on the linear consistent plant (BASELINE config 5), closed loop, against the block oracle.  lanes 0 / 8 / 16: the
+    tuned wide-shape kernel (normal-equation control law); 32 and negative values: the generic template (Householder QR)."""
     from oracle import rmckf_block
     plant = uvs.LinearPlant.random(32, 7, seed=2)
     K, T = 80, 4
@@ -302,14 +304,35 @@ def test_closed_loop_stress_plant(uvs, lanes):
     q0 = q_goal + rng.uniform(-0.15, 0.15, (T, 7))
     noise = rng.standard_t(3, size=(T, K, 32)) * 0.5
     x0 = np.tile((plant.J * (1 + 0.1 * rng.normal(size=plant.J.shape))).ravel(), (T, 1))
-    fp = uvs.engine.make_params(32, 7, 'GMCKF', 10.0, False, 0.05, 15, 0.2, des, False, lanes, steps=K)
+    fp = uvs.engine.make_params(32, 7, method, 10.0, False, 0.05, 15, 0.2, des, False, lanes, steps=K)
     out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), _cuda(x0), want=('x', 'err', 'q'))
+    assert not out['status'].cpu().numpy().any() and np.all(out['k_done'].cpu().numpy() == K)
     for t in range(T):
-        ref = rmckf_block.run_closed_loop(plant.features, q0[t], des, noise[t], 0.05, 0.05 * (K + 0.5), 0.2, x0[t], initial_guess=False)
+        ref = rmckf_block.run_closed_loop(plant.features, q0[t], des, noise[t], 0.05, 0.05 * (K + 0.5), 0.2, x0[t], method=method, initial_guess=False)
         assert ref['k_done'] == K and ref['status'] == 0
         assert rel_err(out['err'].cpu().numpy()[:, :, t], ref['err']) <= 1e-8
         assert rel_err(out['q'].cpu().numpy()[:, :, t], ref['q']) <= 1e-8
         assert rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']) <= 1e-8
+
+
+def test_closed_loop_stress_plant_record_layout(uvs):
+    """Per-trial records ([step][trial][component]): the wide-shape kernel sends X through its LDS transposition (1 KB stores).  Same
+    numbers as the trial-fastest layout bit for bit, whole wavefronts (T = 24) and a ragged batch (T = 21, plain store path) alike."""
+    plant = uvs.LinearPlant.random(32, 7, seed=2)
+    K = 40
+    rng = np.random.default_rng(8)
+    q_goal = plant.q0 + rng.uniform(-0.3, 0.3, 7)
+    des = plant.features(q_goal)
+    for T in (24, 21):
+        q0 = q_goal + rng.uniform(-0.15, 0.15, (T, 7))
+        noise = rng.standard_t(3, size=(K, 32, T)) * 0.5
+        x0 = np.tile((plant.J * (1 + 0.1 * rng.normal(size=plant.J.shape))).ravel(), (T, 1))
+        fp = uvs.engine.make_params(32, 7, 'GMCKF', 10.0, True, 0.05, 15, 0.2, des, False, 0, steps=K)
+        a = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise), _cuda(x0), want=('x', 'err', 'q'), layout='kct')
+        b = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise.transpose(0, 2, 1)), _cuda(x0), want=('x', 'err', 'q'), layout='ktc')
+        for key in ('x', 'err', 'q'):
+            assert np.array_equal(uvs.engine.as_tkc(a[key], 'kct').cpu().numpy(), uvs.engine.as_tkc(b[key], 'ktc').cpu().numpy()), (T, key)
+        assert np.array_equal(a['stats'].cpu().numpy(), b['stats'].cpu().numpy()) and not b['status'].cpu().numpy().any()
 
 
 # ---------------------------------------------------------------------------------------------- failure semantics

@@ -39,6 +39,8 @@ bool closed_tuned_b(int m, int n, int L, int method, bool linear, bool xo, int64
 // role-split closed loop (rmckf_split.hpp): lanes_per_filter = 5
 bool closed_split(int m, int n, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 constexpr int kSplitLanes = 5;
+// tuned wide-shape closed loop (rmckf_wide.hpp): (32,7), lanes_per_filter = 8 (the default of that shape for the closed loop)
+bool closed_wide(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 // generic templates (rmckf_generic.hpp)
 bool closed_generic_a(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 bool closed_generic_b(int m, int n, int L, int method, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);

@@ -479,6 +479,57 @@ UVS_DEV void svd_solve(double (&A)[N][N], const double (&c)[N], double (&sol)[N]
     }
 }
 
+// ---------------------------------------------------------------- normal equations (role-split and wide-shape kernels)
+// G = J^T J = L L^T.  The pivots of the Cholesky factor are the R_cc^2 of the QR of J, so the same spread test marks ill-conditioned
+// Jacobians for the careful second pass -- here already from a spread of 2^20 in |R_cc|, because the error of the normal equations
+// grows with cond(J)^2 (one refinement step squares it again: measured against numpy's pinv 5e-14 relative at cond <= 1.5e3, the same
+// as Householder, 3e-11 at cond 1e5, 6e-9 at cond 1e6).
+constexpr unsigned kSuspectSpreadNormalEq = 40u << 20;
+
+// In place: G[at(j, i)], i > j, becomes L_ij; rs[j] = 1 / L_jj.  Returns the suspect verdict: pivots spread too far, or one of them
+// is not a positive normal number (zero / negative: breakdown; inf / NaN).
+template <int N>
+UVS_DEV bool chol_factor(double (&G)[Sym<N>::NP], double (&rs)[N]) {
+    Spread spread;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double d = G[Sym<N>::at(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = fma(-G[Sym<N>::at(k, j)], G[Sym<N>::at(k, j)], d);
+        spread.add(d);
+        double sq, r;
+        fast_sqrt_rsqrt(d, sq, r);
+        rs[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double v = G[Sym<N>::at(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = fma(-G[Sym<N>::at(k, i)], G[Sym<N>::at(k, j)], v);
+            G[Sym<N>::at(j, i)] = v * r;
+        }
+    }
+    return spread.hi - spread.lo >= kSuspectSpreadNormalEq || spread.lo == 0u || spread.hi >= 0x7ff00000u;
+}
+
+// L z = b, L^T x = z in place; L[at(j, i)] for i > j holds L_ij, rs[j] = 1 / L_jj
+template <int N>
+UVS_DEV void chol_solve_inplace(const double (&L)[Sym<N>::NP], const double (&rs)[N], double (&b)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double v = b[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v = fma(-L[Sym<N>::at(k, j)], b[k], v);
+        b[j] = v * rs[j];
+    }
+#pragma unroll
+    for (int j = N - 1; j >= 0; --j) {
+        double v = b[j];
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) v = fma(-L[Sym<N>::at(j, i)], b[i], v);
+        b[j] = v * rs[j];
+    }
+}
+
 // ---------------------------------------------------------------- control law: dq = -gain * pinv(J) y
 // Overdetermined / square case (M >= N): Householder QR of [J | y] distributed over the L lanes of the
 // group (each lane holds R rows), then back substitution.  Equals numpy's pinv(J) @ y (experiment.py:312)

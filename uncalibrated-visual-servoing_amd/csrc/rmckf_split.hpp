@@ -42,27 +42,6 @@ namespace uvs {
 // numpy's pinv on the reference's own trajectories (cond <= 1.5e3) 5e-14 relative, the same as Householder (2e-14 ... 7e-14), 3e-11 at
 // cond 1e5, 6e-9 at cond 1e6.  The pivots of the Cholesky factor are the R_cc^2 of the QR, so the same spread test marks
 // ill-conditioned Jacobians for the careful second pass, here already from a spread of 2^20 in |R_cc|.
-constexpr unsigned kSuspectSpreadNormalEq = 40u << 20;
-
-template <int N>
-UVS_DEV void chol_solve_inplace(const double (&L)[Sym<N>::NP], const double (&rs)[N], double (&b)[N]) {
-    // L z = b, L^T x = z; L[at(j, i)] for i > j holds L_ij, rs[j] = 1 / L_jj
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double v = b[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v = fma(-L[Sym<N>::at(k, j)], b[k], v);
-        b[j] = v * rs[j];
-    }
-#pragma unroll
-    for (int j = N - 1; j >= 0; --j) {
-        double v = b[j];
-#pragma unroll
-        for (int i = j + 1; i < N; ++i) v = fma(-L[Sym<N>::at(j, i)], b[i], v);
-        b[j] = v * rs[j];
-    }
-}
-
 template <int M, int N, int SX, int SV>
 UVS_DEV bool lstsq_normal_lds(const double (*lx)[SX], const double (*lrhs)[SV], unsigned lane, double (&sol)[N]) {
     constexpr int NP = Sym<N>::NP;
@@ -98,26 +77,8 @@ UVS_DEV bool lstsq_normal_lds(const double (*lx)[SX], const double (*lrhs)[SV], 
             b[l] = fma(xi[l], xi[N], b[l]);
         }
     }
-    // Cholesky in place: G[at(j, i)], i > j, becomes L_ij; the diagonal is kept as 1 / L_jj
     double rs[N];
-    Spread spread;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double d = G[Sym<N>::at(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d = fma(-G[Sym<N>::at(k, j)], G[Sym<N>::at(k, j)], d);
-        spread.add(d);                                           // = R_jj^2 of the QR; <= 0 or NaN when the factorisation breaks down
-        double sq, r;
-        fast_sqrt_rsqrt(d, sq, r);
-        rs[j] = r;
-#pragma unroll
-        for (int i = j + 1; i < N; ++i) {
-            double v = G[Sym<N>::at(j, i)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) v = fma(-G[Sym<N>::at(k, i)], G[Sym<N>::at(k, j)], v);
-            G[Sym<N>::at(j, i)] = v * r;
-        }
-    }
+    const bool suspect = chol_factor<N>(G, rs);
     chol_solve_inplace<N>(G, rs, b);                             // s0
     double c[N];
 #pragma unroll
@@ -148,8 +109,7 @@ UVS_DEV bool lstsq_normal_lds(const double (*lx)[SX], const double (*lrhs)[SV], 
     chol_solve_inplace<N>(G, rs, c);
 #pragma unroll
     for (int j = 0; j < N; ++j) sol[j] = b[j] + c[j];
-    // suspect: pivots spread too far, or one of them is not a positive normal number (zero / negative: breakdown; inf / NaN)
-    return spread.hi - spread.lo >= kSuspectSpreadNormalEq || spread.lo == 0u || spread.hi >= 0x7ff00000u;
+    return suspect;
 }
 
 // Noise-free features of all M rows of one trial per lane at the joints lq[.][lane]: DH chain (ur10_simulation.py:97-110, 204-211) and

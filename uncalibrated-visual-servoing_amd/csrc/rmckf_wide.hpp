@@ -1,0 +1,317 @@
+// Tuned closed-loop kernel for the wide stress shape (BASELINE config 5: m = 32 rows, n = 7 joints, linear consistent plant).
+//
+// Sizing.  A filter is 32 covariance blocks of 28 doubles + 224 doubles of X = 8.96 KB (the reference's dense 224 x 224 P would be
+// 401 KB and cannot exist on chip at all).  L = 8 adjacent lanes share a filter, lane `sub` owning rows sub, sub + 8, sub + 16, sub + 24:
+// 140 doubles of state per lane, so one wavefront per SIMD (512 registers; what does not fit the 256 VALU-addressable ones the compiler
+// parks in AGPRs), 8 trials per wavefront.
+//
+// What differs from the generic template that served this shape before (45-52 ms per 65 536 x 299 sweep):
+//   * control law by the normal equations with one refinement step instead of Householder QR across 16 lanes.  Each lane accumulates
+//     J^T J and J^T y over its own rows, ONE batch of 35 independent group sums follows (the QR needs 35 sums too, but one after the
+//     other, each on the critical path, plus a replicated sqrt / reciprocal chain per column), then every lane factors the 7 x 7
+//     Gram matrix itself; the refinement step costs 7 more sums.  Accuracy: rmckf_device.hpp, "normal equations";
+//   * estimator selected at compile time, rows through the same rmckf_row as the (8,6) kernels;
+//   * plant matrix rows and desired features in LDS, joints replicated on the 8 lanes (no exchange), stream cursors instead of
+//     per-element address arithmetic, next step's noise fetched one step ahead.
+#pragma once
+#include "rmckf_tuned.hpp"
+
+namespace uvs {
+
+// Scheduling fence between the rows of a lane: without it the compiler interleaves the four row updates for instruction-level
+// parallelism, needs ~700 registers and spills to scratch; one wavefront per SIMD gains nothing from that interleaving anyway.
+#ifndef UVS_WIDE_OCC16
+#define UVS_WIDE_OCC16 1
+#endif
+#ifndef UVS_WIDE_NOFENCE
+#define UVS_WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define UVS_WIDE_FENCE() do { } while (0)
+#endif
+
+// v[idx] for a per-lane idx on a register-resident array (a select chain; a variably indexed access would go through scratch memory)
+template <int N>
+UVS_DEV double pick_lane_value(const double (&v)[N], int idx) {
+    double r = v[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) r = (idx == j) ? in_reg(v[j]) : r;
+    return r;
+}
+
+// XREC: the X stream is laid out as per-trial records ([step][trial][component]: comp_stride 1, trial_stride M N).  The TPW trials of a
+// wavefront then own one contiguous block of TPW M N doubles per step (14 KB at (32,7), L = 8): the rows go through LDS once and leave as
+// 16-byte-per-lane stores of 1 KB each, fully coalesced.  In the trial-fastest layout of the (8,6) kernels a wavefront of 8 trials can only
+// write 64-byte pieces (8 trials x 8 B per component row), which is what held the generic template at 50 ms.
+template <int M, int N, int L, int METHOD, bool XOUT, bool XREC>
+__global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loop_wide_kernel(const ClosedArgs A) {
+    static_assert(M % L == 0 && M >= N && (L == 8 || L == 16), "wide kernel: rows interleaved over 8 or 16 adjacent lanes (one DPP row)");
+    constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;
+    constexpr int REC = M * N, RECP = REC + 1;                     // record length, padded in LDS against bank conflicts
+    static_assert(!XREC || (TPW * REC) % 128 == 0, "record path: a whole number of 1 KB stores per wavefront");
+    __shared__ double lJ[M][N];                                    // plant matrix
+    __shared__ double lc[M], ldes[M];                              // f0 - J q0, desired_f
+    __shared__ double lt[XREC ? TPW * RECP : 1];                   // transposition buffer of the X records
+    __shared__ double lacc[3 * R][64], lfp[R][64];                 // lane-private: ISE / IAE / ITAE accumulators, previous noisy features
+    // PV of the lane's R covariance blocks stay in registers, the others live in LDS and pass through registers while their row is
+    // updated: with all four in registers (L = 8) the compiler overflows VGPRs + AGPRs and spills ~60 dwords per lane to scratch
+    constexpr int PV = (L == 8) ? R - 1 : R, PL = R - PV;
+    __shared__ double lp[PL > 0 ? PL * NP : 1][64];
+
+    const unsigned lane = threadIdx.x;
+    const int sub = (int)(lane & (L - 1));
+    const long long wave_first = (long long)blockIdx.x * TPW;
+    const unsigned tl = lane / L;
+    const bool valid = wave_first + tl < A.T;
+    const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial (duplicate values, same addresses)
+    const uvs_filter_params &fp = A.fp;
+    const int K = fp.steps;
+
+    for (int i = (int)lane; i < M; i += 64) {
+        double c = A.plant.lin_f0[i];
+        for (int j = 0; j < N; ++j) {
+            const double v = A.plant.lin_jacobian[i * N + j];
+            lJ[i][j] = v;
+            c = fma(-v, A.plant.lin_q0[j], c);
+        }
+        lc[i] = c;
+        ldes[i] = fp.desired[i];
+    }
+    __syncthreads();
+
+    // stream cursors of this lane's first row (components advance by L rows)
+    const double *pn = A.noise.p ? A.noise.at(trial, 0, sub) : nullptr;
+    // record path: every lane points at the first record of the wavefront (the last, ragged wavefront of a batch takes the plain path)
+    double *px = (XOUT && A.x_out.p) ? (XREC ? A.x_out.at(wave_first, 0, 0) : A.x_out.at(trial, 0, sub * N)) : nullptr;
+    double *pe = A.err_out.p ? A.err_out.at(trial, 0, sub) : nullptr;
+    double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
+    double *pq = (A.q_out.p && sub < N) ? A.q_out.at(trial, 0, sub) : nullptr;           // lane `sub` logs joint `sub`
+    double *pd = (A.dq_out.p && sub < N) ? A.dq_out.at(trial, 0, sub) : nullptr;
+
+    double q[N], dq[N], x[R][N], p[PV][NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { q[j] = *A.q_start.at(trial, 0, j); dq[j] = 0.0; }     // first_run: H = 0 (experiment.py:183-185)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = r * L + sub;
+        lfp[r][lane] = 0.0;                                        // f = zeros(m) (experiment.py:56): no analytic initial guess on this plant
+#pragma unroll
+        for (int j = 0; j < N; ++j) x[r][j] = *A.x0.at(trial, 0, row * N + j);
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+#pragma unroll
+            for (int j = l; j < N; ++j) {
+                const double v = (l == j) ? 1.0 : 0.0;             // P = I (experiment.py:73)
+                if (r < PV) p[r < PV ? r : 0][Sym<N>::at(l, j)] = v;
+                else lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane] = v;
+            }
+        lacc[r][lane] = lacc[R + r][lane] = lacc[2 * R + r][lane] = 0.0;
+    }
+    double nz_next[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) nz_next[r] = (pn && K > 0) ? pn[(long long)r * L * A.noise.sc] : 0.0;
+    if (pn) pn += A.noise.sk;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): keep "nz_next may be in flight" out of the loop header
+
+    double t = fp.dt;
+    int status = UVS_STATUS_SUCCESS, k_done = K;
+    bool alive = true, flagged = false;
+
+    for (int k = 0; k < K; ++k) {
+        double nz[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz[r] = nz_next[r];
+        if (pn && k + 1 < K) {                                     // next step's noise: a whole step to arrive
+#pragma unroll
+            for (int r = 0; r < R; ++r) nz_next[r] = pn[(long long)r * L * A.noise.sc];
+            pn += A.noise.sk;
+        }
+        // ---- plant + measurement (experiment.py:134-135, 170-177, 302)
+        double zi[R], err[R], kap[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = r * L + sub;
+            double f = lc[row];
+#pragma unroll
+            for (int j = 0; j < N; ++j) f = fma(lJ[row][j], q[j], f);
+            f += nz[r];
+            zi[r] = f - lfp[r][lane];
+            err[r] = f - ldes[row];
+            lfp[r][lane] = f;
+        }
+        const double sigma = bandwidth(fp, k);
+        const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
+        double c_shared = 1.0;
+        if constexpr (METHOD == UVS_METHOD_IMCCKF) {               // one weight for the whole filter (experiment.py:258-261)
+            double ss = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(x[r][j], dq[j], pred);
+                const double nu = zi[r] - pred;
+                ss = fma(nu, nu, ss);
+            }
+            c_shared = exp_nonpos(group_sum<L>(ss) * neg_half_inv_s2);
+        }
+        // ---- estimator rows (experiment.py:166-297)
+        double chk = 0.0;
+        double *pxr = px;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            UVS_WIDE_FENCE();
+            if (r < PV) {
+                rmckf_row<N, METHOD>(x[r], p[r < PV ? r : 0], dq, zi[r], neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
+            } else {
+                double pb[NP];
+#pragma unroll
+                for (int e = 0; e < NP; ++e) pb[e] = lp[(r >= PV ? r - PV : 0) * NP + e][lane];
+                rmckf_row<N, METHOD>(x[r], pb, dq, zi[r], neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
+#pragma unroll
+                for (int e = 0; e < NP; ++e) lp[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
+            }
+            if constexpr (XOUT && !XREC) {
+                if (pxr) {
+                    double *pc = pxr;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { *pc = x[r][j]; pc += A.x_out.sc; }
+                    pxr += (long long)L * N * A.x_out.sc;
+                }
+            }
+            if constexpr (XOUT && XREC) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) lt[tl * RECP + (r * L + sub) * N + j] = x[r][j];
+            }
+        }
+        UVS_WIDE_FENCE();
+        if constexpr (XOUT && XREC) {
+            if (px) {
+                // the wavefront's TPW records are one contiguous block: lane l stores doubles 2 l, 2 l + 1 of every 128-double (1 KB) slice
+                double *blk = px + 2 * lane;
+#pragma unroll
+                for (int i = 0; i < TPW * REC / 128; ++i) {
+                    const int d = 128 * i + 2 * (int)lane;         // index inside the block; a pair never straddles two records (REC is even)
+                    const double *src = &lt[(d / REC) * RECP + d % REC];
+                    double2 v;
+                    v.x = src[0];
+                    v.y = src[1];
+                    *reinterpret_cast<double2 *>(blk + 128 * i) = v;
+                }
+            }
+        }
+        (void)pxr;
+        if (px) px += A.x_out.sk;
+        chk = group_sum<L>(chk);
+        if (alive && !(chk == 0.0)) {                              // X turned non-finite: pinv would raise (experiment.py:313-316)
+            alive = false;
+            status = UVS_STATUS_FAIL;
+            k_done = k;
+        }
+        if (!__any(alive)) break;
+
+        // ---- control law dq = -gain pinv(X)(kappa o err) (experiment.py:300-312): normal equations + one refinement step
+        double G[NP], b[N], y[R];
+#pragma unroll
+        for (int e = 0; e < NP; ++e) G[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) b[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            UVS_WIDE_FENCE();
+            y[r] = kap[r] * err[r];
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+#pragma unroll
+                for (int j = l; j < N; ++j) G[Sym<N>::at(l, j)] = fma(x[r][l], x[r][j], G[Sym<N>::at(l, j)]);
+                b[l] = fma(x[r][l], y[r], b[l]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NP; ++e) G[e] = group_sum<L>(G[e]);    // independent sums: they pipeline
+#pragma unroll
+        for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
+        UVS_WIDE_FENCE();
+        double rs[N];
+        const bool suspect = chol_factor<N>(G, rs);
+        flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
+        chol_solve_inplace<N>(G, rs, b);                           // s0
+        double c[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                              // c = J^T (y - J s0)
+            double ri = y[r];
+#pragma unroll
+            for (int j = 0; j < N; ++j) ri = fma(-x[r][j], b[j], ri);
+#pragma unroll
+            for (int j = 0; j < N; ++j) c[j] = fma(x[r][j], ri, c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[j] = group_sum<L>(c[j]);
+        chol_solve_inplace<N>(G, rs, c);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dq[j] = -fp.gain * (b[j] + c[j]);
+
+        // ---- logs and statistics
+        if (pe) {
+            double *pc = pe;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { *pc = err[r]; pc += (long long)L * A.err_out.sc; }
+            pe += A.err_out.sk;
+        }
+        if (pf) {
+            double *pc = pf;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { *pc = lfp[r][lane]; pc += (long long)L * A.f_out.sc; }
+            pf += A.f_out.sk;
+        }
+        if (pq) { *pq = pick_lane_value<N>(q, sub); pq += A.q_out.sk; }
+        if (pd) { *pd = pick_lane_value<N>(dq, sub); pd += A.dq_out.sk; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double e = alive ? err[r] : 0.0;                 // a failed trial stops contributing
+            const double ae = fabs(e);
+            lacc[r][lane] = fma(e, e, lacc[r][lane]);
+            lacc[R + r][lane] += ae;
+            lacc[2 * R + r][lane] = fma(t, ae, lacc[2 * R + r][lane]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) q[j] = fma(dq[j], fp.dt, q[j]);            // new_q = q + dq t_s (experiment.py:320)
+        t += fp.dt;
+    }
+
+    double s2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v = fma(lacc[c * R + r][lane], lacc[c * R + r][lane], v);
+        s2[c] = group_sum<L>(v);
+    }
+    if (!valid) return;
+    if (sub == 0) {
+        if (A.stats) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A.stats[3 * trial + c] = sqrt(s2[c]);
+        }
+        if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
+        if (A.k_done) A.k_done[trial] = k_done;
+    }
+    if (A.x_final.on()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) *A.x_final.at(trial, 0, (r * L + sub) * N + j) = x[r][j];
+    }
+    if (A.p_final.on()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int l = 0; l < N; ++l)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) =
+                        (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
+    }
+}
+
+}  // namespace uvs

@@ -105,7 +105,9 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     // template with |value| lanes (kept as an in-library cross-check of the tuned code).
     const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF) && fp->lanes_per_filter >= 0;
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
+    if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
     if (tuned_ok && L == kSplitLanes) launched = closed_split(fp->m, fp->n, fp->method, linear, xo, T, s, A);
+    if (!launched && tuned_ok) launched = closed_wide(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched && tuned_ok) launched = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
