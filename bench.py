@@ -89,6 +89,24 @@ def _cpu_trial(args):
     return out['k_done'], time.perf_counter() - t0
 
 
+def _cpu_trial_block(args):
+    """Same trial through the per-row (block) numpy restatement, oracle/rmckf_block.py (SURVEY 8d asks for it beside the dense port)."""
+    os.environ['OPENBLAS_NUM_THREADS'] = '1'
+    from oracle import noise_ref, plant_ref, rmckf_block, rmckf_dense
+    seed, q_start = args
+    cfg = config2()
+    ex = cfg['experiments']
+    noise = noise_ref.NoiseStreamRef(8, noise_ref.ALPHA_STABLE, seed, alpha=ALPHA, beta=0, gamma=1, delta=0).take(299)
+    discs = plant_ref.place_discs()
+    robot = plant_ref.PinholeUR10(ex['dt'])
+    robot.start(q_start)
+    x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 8, 6)
+    t0 = time.perf_counter()
+    out = rmckf_block.run_closed_loop(lambda q: plant_ref.project(plant_ref.fkine_all(q)[5], discs), q_start, ex['desired_f'], noise, ex['dt'],
+                                      ex['t_max'], ex['ibvs_gain'], x0, method='GMCKF', kernel_bw=10.0, annealing=False)
+    return out['k_done'], time.perf_counter() - t0
+
+
 def available_cores():
     """Cores this process may really use: the scheduler affinity, cut down to the cgroup CPU quota when the container has one
     (a 256-way affinity mask over a 16-core quota would otherwise report 256 'cores' running at a sixteenth of their speed)."""
@@ -120,7 +138,15 @@ def cpu_baseline(q_starts, budget_trials_per_core=256):
     wall = time.perf_counter() - t0
     updates = sum(r[0] for r in res)
     single = updates / sum(r[1] for r in res)                     # per-process rate (what one reference process achieves)
-    return {'value': updates / wall, 'unit': 'updates/s', 'cores': cores, 'kind': 'port',
+    nb = min(len(jobs), max(cores, n_trials // 4))                # the block form is ~3x slower per trial in numpy (more, smaller calls)
+    t0 = time.perf_counter()
+    with mp.get_context('fork').Pool(cores) as pool:
+        res_b = pool.map(_cpu_trial_block, jobs[:nb], chunksize=1)
+    wall_b = time.perf_counter() - t0
+    block = {'value': sum(r[0] for r in res_b) / wall_b, 'unit': 'updates/s', 'cores': cores,
+             'sample': f'{nb} trials x 299 steps of config 2 through oracle/rmckf_block.py (per-row numpy form, same cores)',
+             'per_process_updates_per_s': sum(r[0] for r in res_b) / sum(r[1] for r in res_b)}
+    return {'value': updates / wall, 'unit': 'updates/s', 'cores': cores, 'kind': 'port', 'block_form': block,
             'sample': f'{n_trials} trials x 299 steps of config 2 through oracle/rmckf_dense.py (dense numpy, OPENBLAS_NUM_THREADS=1, '
                       f'one process per core, noise pre-drawn); os.cpu_count()={os.cpu_count()}, affinity={len(os.sched_getaffinity(0))}, usable (cgroup quota)={cores}',
             'per_process_updates_per_s': single}
@@ -175,6 +201,70 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
     return out
 
 
+def side_config(config, torch, uvs_amd, engine, batch, dev, trials=None, reps=5, warm=2, hold=False, lanes=0):
+    """BASELINE configs 3 and 5 measured in the same run as side objects of the bench line (never as `value`): a few launches of the
+    full-size workload, HIP events on the launch stream around every launch, inputs resident in HBM."""
+    import ctypes as C
+    cfg = config2()
+    K = len(engine.loop_clock(0.05, 15))
+    NV = uvs_amd._lib.NULL_VIEW
+    flat = lambda t: uvs_amd._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))     # noqa: E731
+    if config == 3:
+        T, M, N, layout = trials or 262144, 8, 6, 'kct'
+        cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0, 'rho': 0.1}, hold=bool(hold), hold_time=0.5)
+        cfg['estimator']['estimator_params']['annealing'] = True
+        cfg['experiments']['epoch'] = T
+        plan = batch.plan_trials(cfg, cells=[0.1])
+        noise = batch.device_noise(cfg, plan, 0, T, K, dev)
+        q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
+        fp = engine.make_params(8, 6, 'GMCKF', 10, True, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, lanes)
+        plant, x0 = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct(), None
+        workload = f'BASELINE config 3: 4-feature UR10 closed loop, GMCKF(RMCKF) annealed sigma, Gaussian mixture rho=0.1 mean=50 hold={bool(hold)}, {T} trials x {K} updates, X+err+q logged'
+        kernel = 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>'
+    else:
+        T, M, N, layout = trials or TRIALS_PER_GPU, 32, 7, 'ktc'
+        cfg['experiments']['epoch'] = T
+        plan = batch.plan_trials(cfg, cells=[ALPHA])
+        lin = uvs_amd.LinearPlant.random(M, N, seed=2)
+        rng = np.random.default_rng(5)
+        q_goal = lin.q0 + rng.uniform(-0.3, 0.3, N)
+        desired = lin.features(q_goal)
+        q0 = torch.as_tensor(q_goal + np.random.default_rng(12345).uniform(-0.15, 0.15, (T, N)), device=dev)
+        x0 = torch.as_tensor(np.tile((lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel(), (T, 1)), device=dev)
+        noise = uvs_amd.noise_device.generate(uvs_amd.NoiseType.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), plan.seed, M, K, layout=layout, device=dev)
+        fp = engine.make_params(M, N, 'GMCKF', 10, False, 0.05, 15, 0.2, desired, False, lanes)
+        plant = lin.to_struct(dev)
+        workload = f'BASELINE config 5: synthetic 16-feature / 7-DoF (m=32, n=7) linear plant, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5, {T} trials x {K} updates, X+err+q logged, per-trial records'
+        kernel = 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>'
+    bufs = {k: engine.alloc_stream(T, K, c, layout, dev, zero=True) for k, c in (('x', M * N), ('err', M), ('q', N))}
+    stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    k_done = torch.zeros(T, dtype=torch.int32, device=dev)
+    ms = []
+    for i in range(warm + reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
+            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, layout), NV if x0 is None else flat(x0),
+            engine.stream_view(bufs['x'], layout), engine.stream_view(bufs['err'], layout), engine.stream_view(bufs['q'], layout), NV, NV,
+            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        uvs_amd._lib.check(rc)
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= warm:
+            ms.append(e0.elapsed_time(e1))
+    updates = int(k_done.sum().item())
+    b_alg = 8 * (2 * M + N + M * N)
+    avg = float(np.mean(ms))
+    gbs = updates * b_alg / (avg * 1e-3) / 1e9
+    out = {'workload': workload, 'trials': T, 'updates_per_launch': updates, 'launches_timed': reps, 'avg_kernel_ms': avg, 'min_kernel_ms': float(np.min(ms)),
+           'updates_per_s': updates / (avg * 1e-3), 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+           'frac': gbs / HBM_PEAK_GBS, 'kernel': kernel, 'layout': layout, 'failed_trials': int((status != 0).sum().item())}
+    del bufs, noise
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -187,6 +277,7 @@ def main():
     ap.add_argument('--no-replay', action='store_true', help='skip the replay-mode (estimator kernel) side measurement')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-rank code path (process group, barrier, stats gather) even with one rank: RCCL smoke test on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side', action='store_true', help='skip the config 3 / config 5 side measurements of the default run')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
@@ -348,13 +439,22 @@ def main():
             b_alg = 8 * M                                         # only the noise stream is read; statistics are 24 B per trial
         avg_ms = float(np.mean(kernel_ms))
         achieved = updates_per_launch * b_alg / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, tr_src = None, None
         tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2) and not args.stats_only:
-            traffic = json.load(open(tr_path)).get('hbm_bytes_per_launch')     # rocprofv3 PMC, measured on exactly this launch shape
+            tr = json.load(open(tr_path))
+            traffic = tr.get('hbm_bytes_per_launch')                # rocprofv3 PMC, measured on exactly this launch shape -- a committed
+            tr_src = f"profiles/traffic_latest.json (round {tr.get('round')}, {tr.get('source')}): rocprofv3 PMC passes of this launch shape, not a measurement of this run"
         replay = None
         if world == 1 and args.config == 2 and not args.no_replay and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
             replay = replay_side_measurement(torch, engine, uvs_amd, fp, bufs['x'], bufs['err'], T, K, M, N)
+        side = {}
+        if world == 1 and args.config == 2 and not args.no_side and not args.stats_only and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
+            for key in list(bufs):
+                bufs[key] = None                                   # 9.7 GB of config-2 streams: make room for 44 GB (config 3) / 41 GB (config 5)
+            torch.cuda.empty_cache()
+            side['config3'] = side_config(3, torch, uvs_amd, engine, batch, dev)
+            side['config5'] = side_config(5, torch, uvs_amd, engine, batch, dev)
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -365,10 +465,11 @@ def main():
                                    f'{T} trials/GPU x {K} updates, ' + ('statistics only (no per-step streams)' if args.stats_only else 'X+err+q logged per step'), 'trials_per_gpu': T, 'updates_per_trial': K,
                        'lanes_per_filter': args.lanes or engine.supported_lanes(M, N)[0], 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
+                         'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
             'cpu_baseline': cpu,
             'replay': replay,
+            'config3': side.get('config3'), 'config5': side.get('config5'),
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},

@@ -65,7 +65,7 @@ def test_replay_matches_reference(uvs, name, lanes):
 
 
 @pytest.mark.parametrize('lanes', [0, 4])
-@pytest.mark.parametrize('name', [n for n in CLOSED if 'closed_mckf' not in n])
+@pytest.mark.parametrize('name', CLOSED)
 def test_estimator_only_replay_matches_reference(uvs, name, lanes):
     """No commanded dq requested: the library runs the register-resident estimator kernel (four lanes per filter, blocked lane mapping, two
     wavefronts per SIMD).  Same gates as the full replay, ragged batch (35 trials = 2 full wavefronts of 16 + 3), and agreement with the
@@ -112,6 +112,8 @@ def test_estimator_only_replay_fail_semantics(uvs):
 def test_closed_loop_matches_reference(uvs, name, lanes):
     """Whole trial in the kernel (plant + estimator + control) on the reference's noise: trajectories within 1e-8."""
     g = load_golden(name)
+    if lanes == 5 and g['meta']['method'] == 'MCKF':
+        pytest.skip('the role-split variant has no MCKF rows')
     K = len(g['t'])
     fp = _fp(uvs, g, lanes)
     plant = uvs.SyntheticPlant.ur10(g['desired'])
@@ -187,9 +189,10 @@ def test_analytical_is_refused_loudly(uvs):
         uvs.Experiment([0] * 6, [0] * 8, None, 0.05, 15, 0.2, uvs.SyntheticRobot(), uvs.Method.ANALYTICAL).run()
 
 
-@pytest.mark.parametrize('lanes', [-1, -2, 4, 8])
+@pytest.mark.parametrize('lanes', [0, 2, -1, -2, 4, 8])
 def test_mckf_fixed_point_iterations_match_block_oracle(uvs, lanes):
-    """A tight threshold forces several fixed-point passes (Cholesky factor, Cx != I) and an epoch cap that skips corrections."""
+    """A tight threshold forces several fixed-point passes (Cholesky factor, Cx != I) and an epoch cap that skips corrections.  Lanes 0 / 2:
+    the tuned kernels run the first pass only, mark the trial, and the library's second pass (generic template) iterates."""
     from oracle import rmckf_block
     g = load_golden('closed_mckf_a1p5')
     meta = g['meta']

@@ -1,23 +1,35 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/<round>/ on the GPU box.  usage: tools/profile_round.sh <outdir under gpurun_out>
-# Kernel-trace statistics and PMC counters are separate passes (never --pmc together with other trace domains).
+# Kernel-trace statistics and PMC counters are separate passes (never --pmc together with other trace domains); the program after
+# `--` is python3 itself.  The traced command is the driver's: bench.py --steps 20 --warmup 5 (minus the host CPU baseline).
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_bench.log 2>&1
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  tag=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$tag.log 2>&1
+# the un-profiled line first: a profiled run clocks 2-3 % lower (MI355X_MICROARCH.md, DVFS give-back)
+python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
+echo "bench line done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats_bench.err
+echo "kernel trace done"
+for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$pass -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$pass.log 2>&1
+  echo "pmc $pass done"
+done
+i=0
+for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_sq$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq$i.log 2>&1
+  echo "pmc sq$i done"
 done
 cd $REPO
-f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1)
-cp $f $OUT/kernel_stats.csv
-(for tag in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do python3 tools/pmc_summary.py $OUT/pmc_$tag closed_loop; python3 tools/pmc_summary.py $OUT/pmc_$tag replay_tuned; python3 tools/pmc_summary.py $OUT/pmc_$tag replay_rows; python3 tools/pmc_summary.py $OUT/pmc_$tag noise_kernel; done) > $OUT/pmc_summary.txt
-python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
-head -8 $OUT/kernel_stats.csv | cut -c1-200
-cat $OUT/pmc_summary.txt
-tail -c 600 $OUT/bench_line.json
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_all_dispatches.csv
+python3 tools/trace_summary.py $OUT/stats --skip closed_loop_tuned_kernel:5 closed_loop_wide_kernel:2 replay_tuned_kernel:1 replay_rows_kernel:1 > $OUT/kernel_trace_summary.csv
+(for tag in FETCH_SIZE WRITE_SIZE sq1 sq2 sq3; do for k in closed_loop_tuned closed_loop_wide replay_tuned replay_rows noise_kernel; do python3 tools/pmc_summary.py $OUT/pmc_$tag $k; done; done) > $OUT/pmc_summary.txt
+cat $OUT/kernel_trace_summary.csv
+head -60 $OUT/pmc_summary.txt
+tail -c 2500 $OUT/bench_line.json
 # keep only the summaries in the merged output
-rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU
+rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3

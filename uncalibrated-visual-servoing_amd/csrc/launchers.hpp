@@ -8,7 +8,7 @@
 
 // (m, n, lanes-per-filter) instantiations of the generic templates; the first listed L of a shape is its default.
 #ifdef UVS_QUICK                      // experiment builds (make quick): the headline shape only, compiles in seconds
-#define UVS_SHAPES_A(X) X(8, 6, 2)
+#define UVS_SHAPES_A(X) X(8, 6, 2) X(8, 6, 4)
 #define UVS_SHAPES_B(X)
 #define UVS_TUNED_SHAPES_A(X) X(8, 6, 2)
 #define UVS_TUNED_SHAPES_B(X)
@@ -21,10 +21,10 @@
 #define UVS_SHAPES(X) UVS_SHAPES_A(X) UVS_SHAPES_B(X)
 // one careful (numpy-pinv) instantiation of the generic closed-loop / replay kernels per shape: the second pass over suspect trials
 #ifdef UVS_QUICK
-#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 2)
+#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 4)
 #define UVS_CAREFUL_SHAPES_B(X)
 #else
-#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 2) X(2, 6, 1)
+#define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 4) X(2, 6, 1)
 #define UVS_CAREFUL_SHAPES_B(X) X(6, 6, 2) X(32, 7, 16)
 #endif
 #define UVS_TUNED_REPLAY_SHAPES(X) X(8, 6) X(6, 6)

@@ -105,6 +105,17 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
         }
         double kap[R], err[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
+        FpiProbe fpi;
+        if constexpr (METHOD == UVS_METHOD_MCKF) {
+            mckf_underflow_prepass<R>(fpi, [&](int r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(lds_x[r * N + j][lane], dq[j], pred);
+                const double nu = (f[r] - f_prev[r]) - pred;
+                return (nu * nu) * neg_half_inv_s2;
+            });
+            fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
+        }
         double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
             for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
 #pragma unroll
             for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
+            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
 #pragma unroll
             for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
             if constexpr (XOUT) {
@@ -140,6 +151,11 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
             k_done = k;
         }
         if (!__any(alive)) break;
+        if constexpr (METHOD == UVS_METHOD_MCKF) {               // first fixed-point pass not conclusive: the careful second pass redoes the trial
+            fpi.num = pair_sum<L>(fpi.num);
+            fpi.den = pair_sum<L>(fpi.den);
+            flagged |= alive && fpi_needs_more(fpi, fp);
+        }
 
         if (on_err) {
             double *po = pe;
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), see replay_tuned_kernel
 
     int status = UVS_STATUS_SUCCESS, k_done = K;
-    bool alive = true;
+    bool alive = true, flagged = false;                          // flagged (MCKF): a step needs more than the first fixed-point pass
     for (int k = 0; k < K; ++k) {
         double f[R], dq[N];
 #pragma unroll
@@ -299,13 +315,24 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
         }
         double kap[R], err[R];
         double chk = 0.0;
+        FpiProbe fpi;
+        if constexpr (METHOD == UVS_METHOD_MCKF) {
+            mckf_underflow_prepass<R>(fpi, [&](int r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(x[r][j], dq[j], pred);
+                const double nu = (f[r] - f_prev[r]) - pred;
+                return (nu * nu) * neg_half_inv_s2;
+            });
+            fpi.skip = blocked_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
+        }
         double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double zi = f[r] - f_prev[r];
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];
-            rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
+            rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
             if constexpr (XOUT) {
                 double *pcx = pxr;
 #pragma unroll
@@ -319,6 +346,11 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
             alive = false;
             status = UVS_STATUS_FAIL;
             k_done = k;
+        }
+        if constexpr (METHOD == UVS_METHOD_MCKF) {
+            fpi.num = blocked_sum<L>(fpi.num);
+            fpi.den = blocked_sum<L>(fpi.den);
+            flagged |= alive && fpi_needs_more(fpi, fp);
         }
         // no early exit when every trial of the wavefront has failed: a path that skips the err stores would make the compiler's
         // in-order vmcnt for the prefetched inputs count only the X stores and wait for the rest, every step
@@ -338,7 +370,7 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
 
     if (!valid) return;
     if (sub == 0) {
-        if (A.status) A.status[trial] = status;
+        if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
         if (A.k_done) A.k_done[trial] = k_done;
     }
     if (A.x_final.on()) {

@@ -107,9 +107,43 @@ UVS_DEV double pick_sub(const double *v, int sub) {
 // state update, rank-1 Joseph downdate.  x: row i of X; pb: its packed covariance block; dq: the regressor (the previous command);
 // zi: the row's measurement f_i - f_old_i.  chk accumulates 0 * x so that it turns NaN as soon as an entry of X is non-finite.
 // Shared by the tuned closed-loop kernel and both tuned replay kernels.
+// What the first pass of the fixed-point MCKF (experiment.py:194-250) leaves for the convergence test ||Xc - X|| / ||X|| <= fpi_threshold
+// (:244, norms over ALL rows of the filter): the lane's share of both squared norms, and whether a correntropy weight underflowed to 0
+// (inv(Cy) raises in the reference and the correction is skipped, :231-236).
+struct FpiProbe {
+    double num = 0.0, den = 0.0;                                 // num = +inf: not decidable here, leave the trial to the careful pass
+    bool skip = false;                                           // a weight Cy underflowed to 0: the whole correction of this step is skipped
+};
+// exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.13321910194...; between the two bounds the kernels do not decide themselves
+constexpr double kExpZeroBelow = -745.14, kExpNonzeroAbove = -745.13;
+
+// Pre-pass of an MCKF step over the lane's rows: innovation of every row against the prior state, to find out whether some Cy is
+// exactly 0 -- inv(Cy) then raises in the reference and the step keeps only the prediction (experiment.py:225-236; with Cauchy-like noise
+// that is 1-2 % of the steps, it is not an exotic path).  `probe(r)` returns nu_r^2 * (-1 / (2 sigma^2)), the argument of the weight.
+template <int R, typename ArgOfRow>
+UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
+    bool zero = false, unsure = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double a = arg_of_row(r);
+        zero |= a < kExpZeroBelow;
+        unsure |= !(a < kExpZeroBelow) && !(a > kExpNonzeroAbove);    // NaN lands here as well; the finiteness probe FAILs the trial anyway
+    }
+    fpi.skip = zero;
+    if (unsure) fpi.num = __builtin_huge_val();
+}
+// Verdict after the rows of a step (num / den summed over the lanes of the filter): true when the first pass is not the whole story --
+// a second fixed-point pass would run, the correction would be skipped, or the test is too close to call in different rounding.  The
+// tuned kernels then mark the trial and the careful second pass (generic template, full fixed-point iteration) redoes it.  On the
+// reference's own configuration (threshold 0.1) every step of every fixture converges in the first pass.
+UVS_DEV bool fpi_needs_more(const FpiProbe &f, const uvs_filter_params &fp) {
+    const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
+    return fp.fpi_epoch_max <= 1 || !(f.num <= thr2 * f.den * (1.0 - 1e-9));
+}
+
 template <int N, int METHOD>
 UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
-                       double reg, double &kap, double &chk) {
+                       double reg, double &kap, double &chk, FpiProbe &fpi) {
     double g[N];
     double pred = 0.0;
 #pragma unroll
@@ -141,6 +175,17 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 #endif
         const double d = kap + reg;                              // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
         gamma = d * fast_rcp(fma(a, d, 1.0));
+    } else if constexpr (METHOD == UVS_METHOD_MCKF) {
+        // first fixed-point pass: Xc = X, so Cx = I and P_hat = P; gain = 1 / (a + 1 / Cy) (experiment.py:225-242).  The state update
+        // and the Joseph form below are then exactly those of the other estimators; kappa of the control law is 1 (:303-308)
+        const double cy = exp_nonpos((nu * nu) * neg_half_inv_s2);
+        gamma = fpi.skip ? 0.0 : cy * fast_rcp(fma(a, cy, 1.0));  // skipped correction: X stays, P keeps the prediction (gamma = 0 below)
+        kap = 1.0;
+        double gg = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { gg = fma(g[j], g[j], gg); fpi.den = fma(x[j], x[j], fpi.den); }
+        const double s = gamma * nu;
+        fpi.num = fma(s * s, gg, fpi.num);                       // ||K (Z - H X)||^2 of this row (0 when skipped: no second pass then)
     } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {          // K = c P H^T (c H P H^T + R)^-1 (experiment.py:262-264)
         kap = 1.0;
         gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
@@ -165,6 +210,14 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 #else
     pb[0] = fma(-beta, g[0], pb[0]);
 #endif
+}
+
+template <int N, int METHOD>
+UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
+                       double reg, double &kap, double &chk) {
+    static_assert(METHOD != UVS_METHOD_MCKF, "MCKF rows need the fixed-point probe");
+    FpiProbe unused;
+    rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, reg, kap, chk, unused);
 }
 
 // Householder QR least squares, rows interleaved over the L lanes of a filter: local row r of lane s is global row r*L + s.
@@ -536,6 +589,17 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
         }
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
+        FpiProbe fpi;
+        if constexpr (METHOD == UVS_METHOD_MCKF) {
+            mckf_underflow_prepass<R>(fpi, [&](int r) {
+                double pred = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) pred = fma(XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane], dq[j], pred);
+                const double nu = ((z[r] + nz[r]) - f_prev[r]) - pred;
+                return (nu * nu) * neg_half_inv_s2;
+            });
+            fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;  // one underflowed weight anywhere in the filter skips every row's correction
+        }
         double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -547,7 +611,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             for (int j = 0; j < N; ++j) x[j] = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
 #pragma unroll
             for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
+            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (XREG) xr[r][j] = x[j];
@@ -581,6 +645,11 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             k_done = k;
         }
         if (!__any(alive)) break;
+        if constexpr (METHOD == UVS_METHOD_MCKF) {               // did the first fixed-point pass settle it (experiment.py:244)?
+            fpi.num = pair_sum<L>(fpi.num);
+            fpi.den = pair_sum<L>(fpi.den);
+            flagged |= alive && fpi_needs_more(fpi, fp);
+        }
 
         // ---- control law: dq = -gain * pinv(X) (kappa o err) (experiment.py:300-312)
         double err[R];

@@ -28,6 +28,7 @@ bool uvs_launch::replay_tuned(int m, int n, int method, bool xo, bool cmd, int64
 #define XR(M, N) \
     if (m == M && n == N) { \
         if (method == UVS_METHOD_GMCKF) tuned2<M, N, UVS_METHOD_GMCKF>(xo, cmd, grid_for(T, 2), s, A); \
+        else if (method == UVS_METHOD_MCKF) tuned2<M, N, UVS_METHOD_MCKF>(xo, cmd, grid_for(T, 2), s, A); \
         else if (method == UVS_METHOD_IMCCKF) tuned2<M, N, UVS_METHOD_IMCCKF>(xo, cmd, grid_for(T, 2), s, A); \
         else tuned2<M, N, UVS_METHOD_KF>(xo, cmd, grid_for(T, 2), s, A); \
         return true; \
@@ -41,6 +42,7 @@ bool uvs_launch::replay_tuned(int m, int n, int method, bool xo, bool cmd, int64
 bool uvs_launch::replay_rows(int m, int n, int method, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A) {
     if (m != 8 || n != 6) return false;
     if (method == UVS_METHOD_GMCKF) rows2<8, 6, UVS_METHOD_GMCKF>(xo, eo, grid_for(T, 4), s, A);
+    else if (method == UVS_METHOD_MCKF) rows2<8, 6, UVS_METHOD_MCKF>(xo, eo, grid_for(T, 4), s, A);
     else if (method == UVS_METHOD_IMCCKF) rows2<8, 6, UVS_METHOD_IMCCKF>(xo, eo, grid_for(T, 4), s, A);
     else rows2<8, 6, UVS_METHOD_KF>(xo, eo, grid_for(T, 4), s, A);
     return true;

@@ -35,9 +35,9 @@ int check_launch(const char *what) {
 }
 
 int default_lanes(int m, int n, int method) {
-    // MCKF carries the Cholesky factors of its blocks through the fixed-point passes: at two lanes per filter (4 blocks per lane) that
-    // state goes to scratch (31 ms per 65 536 x 299 sweep), at four lanes it stays in registers (8 ms)
-    if (method == UVS_METHOD_MCKF && m == 8 && n == 6) return 4;
+    // (MCKF: the tuned two-lane kernels run the first fixed-point pass and leave trials that need more to the careful second pass,
+    // whose generic template carries the Cholesky factors of the blocks -- four lanes per filter there, at two they go to scratch)
+    (void)method;
 #define X(M, N, L) if (m == M && n == N) return L;
     UVS_SHAPES(X)
 #undef X
@@ -103,7 +103,8 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     bool launched = false;
     // lanes_per_filter 1 / 2 / 4 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic
     // template with |value| lanes (kept as an in-library cross-check of the tuned code).
-    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF) && fp->lanes_per_filter >= 0;
+    const bool tuned_ok = (fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF ||
+                           (fp->method == UVS_METHOD_MCKF && L == 2)) && fp->lanes_per_filter >= 0;
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
     if (tuned_ok && L == kSplitLanes) launched = closed_split(fp->m, fp->n, fp->method, linear, xo, T, s, A);
@@ -125,7 +126,8 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     int L = 0;
     if (int rc = check_params(fp, T, &L)) return rc;
     if (!f.base || !dq.base || !x0.base) return fail(UVS_ERR_ARG, "%s", "f, dq and x0 views are required");
-    if (dqcmd_out.base && !status) return fail(UVS_ERR_ARG, "%s", "status is required when the commanded dq is requested (it carries the suspect marks between the two passes)");
+    if ((dqcmd_out.base || fp->method == UVS_METHOD_MCKF) && !status)
+        return fail(UVS_ERR_ARG, "%s", "status is required when the commanded dq is requested or the estimator is MCKF (it carries the marks between the two passes)");
     uvs::ReplayArgs A;
     A.fp = *fp;
     A.T = T;
@@ -136,7 +138,8 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
     // two lanes per filter (the default) at (8,6): tuned kernel; a negative lanes_per_filter forces the generic template
-    const bool tuned_method = fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF;
+    const bool tuned_method = fp->method == UVS_METHOD_GMCKF || fp->method == UVS_METHOD_KF || fp->method == UVS_METHOD_IMCCKF ||
+                              fp->method == UVS_METHOD_MCKF;
     const bool tuned_ok = tuned_method && fp->lanes_per_filter >= 0 && L == 2;
     // without the commanded dq there is no least-squares solve and nothing couples a filter's rows: four lanes per filter, state in
     // registers, two wavefronts per SIMD (library default, or lanes_per_filter = 4)
@@ -146,7 +149,7 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     if (!launched) launched = replay_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || replay_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
     if (int rc = check_launch("replay_kernel")) return rc;
-    if (dqcmd_out.base) {                                          // the control law ran: careful second pass over the suspect trials
+    if (dqcmd_out.base || fp->method == UVS_METHOD_MCKF) {         // control law ran / first-pass MCKF rows: careful second pass over the marked trials
         if (!(replay_careful_a(fp->m, fp->n, T, s, A) || replay_careful_b(fp->m, fp->n, T, s, A)))
             return fail(UVS_ERR_SHAPE, "%s", "(m, n) has no careful replay instantiation in libuvs_rmckf");
         return check_launch("replay_kernel (careful pass)");
