@@ -32,4 +32,6 @@ cat $OUT/kernel_trace_summary.csv
 head -60 $OUT/pmc_summary.txt
 tail -c 2500 $OUT/bench_line.json
 # keep only the summaries in the merged output
+head -2 $(ls $OUT/stats/*/*kernel_trace.csv | head -1) | cut -c1-600
+head -2 $(ls $OUT/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1) | cut -c1-600
 rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3

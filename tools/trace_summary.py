@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel duration statistics from a rocprofv3 --kernel-trace CSV, warm-up dispatches excluded.
+"""Per-kernel (and per grid size: the same kernel serves BASELINE configs 2 and 3) duration statistics from a rocprofv3 --kernel-trace CSV, warm-up dispatches excluded.
 
 usage: tools/trace_summary.py <dir with *kernel_trace.csv> [--skip name:count ...]
 For every kernel: calls, mean / median / min / max over ALL dispatches and over the dispatches that remain after dropping the first
@@ -15,7 +15,8 @@ skip = dict((a.split(':')[0], int(a.split(':')[1])) for a in sys.argv[3:]) if le
 rows = collections.defaultdict(list)
 for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        rows[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+        grid = r.get('Grid_Size_X') or r.get('Grid_Size') or '?'
+        rows[r['Kernel_Name'] + ' grid=' + str(grid)].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
 print('kernel,calls,mean_all_ms,skipped,mean_ms,median_ms,min_ms,max_ms')
 for name, v in sorted(rows.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
     if not name.startswith('void uvs::') and 'uvs::' not in name:
@@ -24,5 +25,5 @@ for name, v in sorted(rows.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
     dur = [x[1] / 1e6 for x in v]
     n_skip = max([c for k, c in skip.items() if k in name] + [0])
     kept = dur[n_skip:] if len(dur) > n_skip else dur
-    short = name.replace('void ', '').split('(')[0]
+    short = name.replace('void ', '').split('(')[0] + ' ' + name.split(' ')[-1]
     print(f'"{short}",{len(dur)},{statistics.mean(dur):.4f},{len(dur) - len(kept)},{statistics.mean(kept):.4f},{statistics.median(kept):.4f},{min(kept):.4f},{max(kept):.4f}')
