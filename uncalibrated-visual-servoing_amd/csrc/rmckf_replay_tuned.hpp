@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
                 return (nu * nu) * neg_half_inv_s2;
             });
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
+            fpi.unsure = pair_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0;
         }
         double *pxr = px;
 #pragma unroll
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
                 return (nu * nu) * neg_half_inv_s2;
             });
             fpi.skip = blocked_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
+            fpi.unsure = blocked_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0;
         }
         double *pxr = px;
 #pragma unroll

@@ -113,6 +113,8 @@ UVS_DEV double pick_sub(const double *v, int sub) {
 struct FpiProbe {
     double num = 0.0, den = 0.0;                                 // num = +inf: not decidable here, leave the trial to the careful pass
     bool skip = false;                                           // a weight Cy underflowed to 0: the whole correction of this step is skipped
+    bool unsure = false;                                         // ... or sits so close to the underflow that only the careful pass may decide
+    double row_gamma = 0.0, row_a = 0.0, row_nu = 0.0;           // first-pass gain, h.P h and innovation of the row just processed
 };
 // exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.13321910194...; between the two bounds the kernels do not decide themselves
 constexpr double kExpZeroBelow = -745.14, kExpNonzeroAbove = -745.13;
@@ -130,7 +132,7 @@ UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
         unsure |= !(a < kExpZeroBelow) && !(a > kExpNonzeroAbove);    // NaN lands here as well; the finiteness probe FAILs the trial anyway
     }
     fpi.skip = zero;
-    if (unsure) fpi.num = __builtin_huge_val();
+    fpi.unsure = unsure;
 }
 // Verdict after the rows of a step (num / den summed over the lanes of the filter): true when the first pass is not the whole story --
 // a second fixed-point pass would run, the correction would be skipped, or the test is too close to call in different rounding.  The
@@ -138,7 +140,129 @@ UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
 // reference's own configuration (threshold 0.1) every step of every fixture converges in the first pass.
 UVS_DEV bool fpi_needs_more(const FpiProbe &f, const uvs_filter_params &fp) {
     const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
-    return fp.fpi_epoch_max <= 1 || !(f.num <= thr2 * f.den * (1.0 - 1e-9));
+    return f.unsure || fp.fpi_epoch_max <= 1 || !(f.num <= thr2 * f.den * (1.0 - 1e-9));
+}
+
+// ---- second and later fixed-point passes of the MCKF (experiment.py:215-245), one row (block) at a time on a lane's registers.
+// Undo of the optimistic first-pass commit of rmckf_row: from (x_new, P_new) and the row's gamma, a, nu back to the prior x and the
+// predicted block P + Q, and the first-pass gain row k1 = gamma (P + Q) h.  P_new h = g (1 - beta a) gives g without a second copy of P.
+template <int N>
+UVS_DEV void mckf_undo_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&h)[N], double gamma, double a, double nu, double (&k1)[N]) {
+    const double beta = gamma * (2.0 - gamma * (a + 1.0));
+    const double inv = fast_rcp(1.0 - beta * a);                // (1 - gamma a)^2 + gamma^2 a > 0
+    double g[N];
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], h[j], acc);
+        g[l] = acc * inv;
+    }
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        const double w = beta * g[l];
+#pragma unroll
+        for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(w, g[j], pb[Sym<N>::at(l, j)]);
+        k1[l] = g[l] * gamma;
+        x[l] = fma(-k1[l], nu, x[l]);
+    }
+}
+// One further pass for one row: current iterate xc = x + k nu0 -> new gain row kn (same arithmetic as Rows::update_mckf in
+// rmckf_device.hpp, which the careful / generic kernels run).  Adds this row's share of ||xn - xc||^2 and ||xc||^2; bad: a weight Cy is 0.
+template <int N>
+UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::NP], const double (&h)[N], double zi, double neg_half_inv_s2,
+                              const double (&k)[N], double (&kn)[N], double &num, double &den, bool &bad) {
+    double Lc[Sym<N>::NP];                                       // lower Cholesky factor of the predicted block, packed
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double dsum = pp[Sym<N>::at(j, j)];
+#pragma unroll
+        for (int k2 = 0; k2 < j; ++k2) dsum = fma(-Lc[Sym<N>::at(k2, j)], Lc[Sym<N>::at(k2, j)], dsum);
+        double ljj, rl;
+        fast_sqrt_rsqrt(dsum, ljj, rl);
+        Lc[Sym<N>::at(j, j)] = rl;                               // the diagonal keeps 1 / L_jj: only reciprocals of it are ever needed
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double v = pp[Sym<N>::at(j, i)];
+#pragma unroll
+            for (int k2 = 0; k2 < j; ++k2) v = fma(-Lc[Sym<N>::at(k2, i)], Lc[Sym<N>::at(k2, j)], v);
+            Lc[Sym<N>::at(j, i)] = v * rl;
+        }
+    }
+    double nu0 = zi, xc[N], ex[N], t[N], g[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) nu0 = fma(-x[j], h[j], nu0);    // prior innovation (the gain is applied to it, experiment.py:242)
+#pragma unroll
+    for (int j = 0; j < N; ++j) xc[j] = fma(k[j], nu0, x[j]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                // L ex = x - xc
+        double v = x[i] - xc[i];
+#pragma unroll
+        for (int k2 = 0; k2 < i; ++k2) v = fma(-Lc[Sym<N>::at(k2, i)], ex[k2], v);
+        ex[i] = v * Lc[Sym<N>::at(i, i)];
+    }
+    double ez = zi;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ez = fma(-xc[j], h[j], ez);
+    const double cy = exp_nonpos((ez * ez) * neg_half_inv_s2);
+    bad |= (cy == 0.0);
+    double ljj[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ljj[j] = fast_rcp(Lc[Sym<N>::at(j, j)]);       // L_jj back from its reciprocal
+#pragma unroll
+    for (int j = 0; j < N; ++j) {                                // t = Cx^-1 L^T h
+        double v = ljj[j] * h[j];
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) v = fma(Lc[Sym<N>::at(j, i)], h[i], v);
+        t[j] = v * fast_rcp(exp_nonpos((ex[j] * ex[j]) * neg_half_inv_s2));    // a Cx of 0 gives inf -> NaN state -> the trial FAILs
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                // g = L t = P_hat h
+        double v = ljj[i] * t[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) v = fma(Lc[Sym<N>::at(j, i)], t[j], v);
+        g[i] = v;
+        a = fma(h[i], v, a);
+    }
+    const double gain = cy * fast_rcp(fma(a, cy, 1.0));
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        kn[l] = g[l] * gain;
+        const double d = fma(kn[l], nu0, x[l]) - xc[l];
+        num = fma(d, d, num);
+        den = fma(xc[l], xc[l], den);
+    }
+}
+// Final state of a row after the iteration: x + k nu0 and the Joseph form with a gain row that is no longer gamma (P + Q) h
+// (experiment.py:297): P - k g^T - g k^T + (h.g + 1) k k^T, g = (P + Q) h.
+template <int N>
+UVS_DEV void mckf_commit_row(double (&x)[N], double (&pp)[Sym<N>::NP], const double (&h)[N], double zi, const double (&k)[N], double &chk) {
+    double nu0 = zi, g[N], a = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) nu0 = fma(-x[j], h[j], nu0);
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc = fma(pp[Sym<N>::at(l, j)], h[j], acc);
+        g[l] = acc;
+        a = fma(h[l], acc, a);
+    }
+    const double c2 = a + 1.0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+#pragma unroll
+        for (int j = l; j < N; ++j) {
+            double v = pp[Sym<N>::at(l, j)];
+            v = fma(-k[l], g[j], v);
+            v = fma(-g[l], k[j], v);
+            v = fma(c2 * k[l], k[j], v);
+            pp[Sym<N>::at(l, j)] = v;
+        }
+        x[l] = fma(k[l], nu0, x[l]);
+        chk = fma(x[l], 0.0, chk);
+    }
 }
 
 template <int N, int METHOD>
@@ -186,6 +310,9 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         for (int j = 0; j < N; ++j) { gg = fma(g[j], g[j], gg); fpi.den = fma(x[j], x[j], fpi.den); }
         const double s = gamma * nu;
         fpi.num = fma(s * s, gg, fpi.num);                       // ||K (Z - H X)||^2 of this row (0 when skipped: no second pass then)
+        fpi.row_gamma = gamma;
+        fpi.row_a = a;
+        fpi.row_nu = nu;
     } else if constexpr (METHOD == UVS_METHOD_IMCCKF) {          // K = c P H^T (c H P H^T + R)^-1 (experiment.py:262-264)
         kap = 1.0;
         gamma = c_shared * fast_rcp(fma(c_shared, a, 1.0));
@@ -432,6 +559,9 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
 #endif
 
+#ifdef UVS_MCKF_COUNT
+    int dbg_steps = 0, dbg_lanes = 0, dbg_passes = 0;
+#endif
     for (int k = 0; k < K; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         UVS_STAMP(5);
@@ -599,7 +729,10 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                 return (nu * nu) * neg_half_inv_s2;
             });
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;  // one underflowed weight anywhere in the filter skips every row's correction
+            fpi.skip |= fp.fpi_epoch_max <= 1;                    // "reached max epoch" after the only pass: correction skipped (:246-250)
+            flagged |= alive && (pair_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0);
         }
+        double m_gamma[R], m_a[R], m_nu[R], m_z[R];              // MCKF: what the undo of a row needs (dead code for the other estimators)
         double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -612,6 +745,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
             for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
             rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
+            if constexpr (METHOD == UVS_METHOD_MCKF) { m_gamma[r] = fpi.row_gamma; m_a[r] = fpi.row_a; m_nu[r] = fpi.row_nu; m_z[r] = zi; }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (XREG) xr[r][j] = x[j];
@@ -638,6 +772,102 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
         // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
         asm volatile("" ::: "memory");
         UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
+        if constexpr (METHOD == UVS_METHOD_MCKF && !XREG) {
+            // ---- did the first fixed-point pass settle it (experiment.py:244)?  Rarely not (0.5 % of the steps under Cauchy noise, none
+            // for alpha >= 1.3 on the reference's configuration): those lanes take their rows back to the prior state, iterate like
+            // Rows::update_mckf and commit the final gain.  The whole wavefront walks through this branch when one of its trials needs it.
+            fpi.num = pair_sum<L>(fpi.num);
+            fpi.den = pair_sum<L>(fpi.den);
+            const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
+            int it = 1;
+            bool more = alive && !fpi.skip && (fpi.num > thr2 * fpi.den);        // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
+#ifdef UVS_MCKF_COUNT
+            dbg_steps += __any(more) ? 1 : 0; dbg_lanes += more ? 1 : 0;
+#endif
+            if (__any(more)) {
+                const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
+                bool skip2 = false;
+                double kk[R][N];
+                if (redo) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {                    // undo the optimistic commit
+                        double x[N], pb[NP];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
+#pragma unroll
+                        for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
+                        mckf_undo_row<N>(x, pb, dq, m_gamma[r], m_a[r], m_nu[r], kk[r]);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
+#pragma unroll
+                        for (int e = 0; e < NP; ++e) {
+                            if (r < PV) p[r < PV ? r : 0][e] = pb[e];
+                            else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
+                        }
+                    }
+                }
+                while (__any(more)) {
+#ifdef UVS_MCKF_COUNT
+                    dbg_passes += 1;
+#endif
+                    double kn[R][N], num2 = 0.0, den2 = 0.0;
+                    bool bad2 = false;
+                    if (more) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            double x[N], pb[NP];
+#pragma unroll
+                            for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
+                            mckf_iterate_row<N>(x, pb, dq, m_z[r], neg_half_inv_s2, kk[r], kn[r], num2, den2, bad2);
+                        }
+                        num2 = pair_sum<L>(num2);
+                        den2 = pair_sum<L>(den2);
+                        const bool hit_zero = pair_sum<L>(bad2 ? 1.0 : 0.0) != 0.0;
+                        if (hit_zero) {                              // inv(Cy) raises: the correction of this step is skipped (:231-236)
+                            skip2 = true;
+                            more = false;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int j = 0; j < N; ++j) kk[r][j] = kn[r][j];
+                            ++it;
+                            if (it == fp.fpi_epoch_max) skip2 = true;                                    // :246-250
+                            more = !skip2 && (num2 > thr2 * den2) && it < fp.fpi_epoch_max;
+                        }
+                    }
+                }
+                if (redo) {
+                    double *pxs = px - UVS_SK(A.x_out.sk);           // this step's rows of the X stream: overwrite the optimistic values
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double x[N], pb[NP];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
+                        if (!skip2) {
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
+                            mckf_commit_row<N>(x, pb, dq, m_z[r], kk[r], chk);
+#pragma unroll
+                            for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) {
+                                if (r < PV) p[r < PV ? r : 0][e] = pb[e];
+                                else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
+                            }
+                        }
+                        if constexpr (XOUT) {
+                            double *pc = pxs + (long long)r * L * N * A.x_out.sc;
+#pragma unroll
+                            for (int j = 0; j < N; ++j) { *pc = x[j]; pc += A.x_out.sc; }
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
         chk = pair_sum<L>(chk);
         if (alive && !(chk == 0.0)) {                            // pinv would raise (experiment.py:313-316)
             alive = false;
@@ -645,7 +875,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             k_done = k;
         }
         if (!__any(alive)) break;
-        if constexpr (METHOD == UVS_METHOD_MCKF) {               // did the first fixed-point pass settle it (experiment.py:244)?
+        if constexpr (METHOD == UVS_METHOD_MCKF && XREG) {       // register-resident variants: first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
             fpi.den = pair_sum<L>(fpi.den);
             flagged |= alive && fpi_needs_more(fpi, fp);
@@ -747,6 +977,10 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
     for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
     if (!valid) return;
+#ifdef UVS_MCKF_COUNT
+    if (A.stats) { A.stats[3 * trial] = dbg_steps; A.stats[3 * trial + 1] = dbg_lanes; A.stats[3 * trial + 2] = dbg_passes; }
+    if (A.stats) return;
+#endif
     if (sub == 0) {
         if (A.stats) {
 #pragma unroll
