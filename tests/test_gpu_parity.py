@@ -409,6 +409,8 @@ def test_monte_carlo_batch_matches_c_oracle(uvs):
     assert np.array_equal(out['status'].cpu().numpy(), ref['status']) and np.array_equal(out['k_done'].cpu().numpy(), ref['k_done'])
     err = out['err'].cpu().numpy().transpose(2, 0, 1)
     dev = np.abs(err - ref['err']).max(axis=(1, 2)) / np.abs(ref['err']).max(axis=(1, 2))
+    print(f'2048-trial batch vs C oracle, 299 steps: relative deviation of the error trajectories median {np.median(dev):.2e}, '
+          f'99 % {np.quantile(dev, 0.99):.2e}, max {dev.max():.2e}')                                 # pytest -s shows it; DESIGN.md quotes it
     assert np.median(dev) <= 1e-11 and np.quantile(dev, 0.99) <= 1e-8 and dev.max() <= 1e-5          # contract: 1e-5 relative
     sdev = np.abs(out['stats'].cpu().numpy() - ref['stats']) / ref['stats']
     assert sdev.max() <= 1e-7
