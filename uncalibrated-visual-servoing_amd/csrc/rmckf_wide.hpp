@@ -106,6 +106,16 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             }
         lacc[r][lane] = lacc[R + r][lane] = lacc[2 * R + r][lane] = 0.0;
     }
+    // record path: where in the (padded) LDS copy the pair of doubles this lane stores with the i-th 1 KB store lives -- computed once,
+    // the division by the record length does not belong in the step loop
+    int src_off[XREC ? TPW * REC / 128 : 1];
+    if constexpr (XREC) {
+#pragma unroll
+        for (int i = 0; i < TPW * REC / 128; ++i) {
+            const int d = 128 * i + 2 * (int)lane;               // index inside the wavefront's block; a pair never straddles two records (REC is even)
+            src_off[i] = (d / REC) * RECP + d % REC;
+        }
+    }
     double nz_next[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) nz_next[r] = (pn && K > 0) ? pn[(long long)r * L * A.noise.sc] : 0.0;
@@ -189,8 +199,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 double *blk = px + 2 * lane;
 #pragma unroll
                 for (int i = 0; i < TPW * REC / 128; ++i) {
-                    const int d = 128 * i + 2 * (int)lane;         // index inside the block; a pair never straddles two records (REC is even)
-                    const double *src = &lt[(d / REC) * RECP + d % REC];
+                    const double *src = &lt[src_off[i]];
                     double2 v;
                     v.x = src[0];
                     v.y = src[1];
