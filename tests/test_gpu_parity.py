@@ -484,3 +484,76 @@ def test_full_size_batch_properties(uvs):
                                           g['desired'], noise[:, :, t].cpu().numpy(), meta['dt'], meta['dt'] * (H + 0.5), meta['gain'], x0)
         assert rel_err(err[:H, :, t].cpu().numpy(), ref['err']) <= 1e-7
     assert int((full['status'] != 0).sum()) < T // 100
+
+
+def test_full_size_config3_properties(uvs):
+    """BASELINE config 3 at its full size (262 144 trials x 299 steps, Gaussian mixture rho = 0.1 / mean 50 from the device generator,
+    annealed sigma): partition invariance and duplicates bit-exact, fused statistics = statistics kernel, sampled trials against the
+    block oracle on the same noise."""
+    import torch
+    import bench
+    from oracle import plant_ref, rmckf_block, rmckf_dense
+    T, K = 262144, 299
+    cfg = bench.config2()
+    cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0, 'rho': 0.1}, hold=False, hold_time=0.5)
+    cfg['estimator']['estimator_params']['annealing'] = True
+    cfg['experiments']['epoch'] = T
+    plan = uvs.batch.plan_trials(cfg, cells=[0.1])
+    noise = uvs.batch.device_noise(cfg, plan, 0, T, K, 'cuda')
+    q0 = torch.as_tensor(plan.q_start.copy(), device='cuda')
+    noise[:, :, T - 1] = noise[:, :, 54321]                                 # a duplicate far away in the grid
+    q0[T - 1] = q0[54321]
+    des = cfg['experiments']['desired_f']
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10, True, 0.05, 15, 0.2, des, True, 0)
+    plant = uvs.SyntheticPlant.ur10(des)
+    full = uvs.engine.closed_loop(fp, plant.to_struct(), q0, noise, want=('err',))
+    err = full['err']
+    assert int(full['status'].sum()) == 0 and bool((full['k_done'] == K).all())
+    assert torch.equal(err[:, :, T - 1], err[:, :, 54321]) and torch.equal(full['stats'][T - 1], full['stats'][54321])
+    lo, hi = 200003, 200003 + 5001
+    part = uvs.engine.closed_loop(fp, plant.to_struct(), q0[lo:hi].contiguous(), noise[:, :, lo:hi].contiguous(), want=('err',))
+    assert torch.equal(part['err'], err[:, :, lo:hi]) and torch.equal(part['stats'], full['stats'][lo:hi])
+    s2 = uvs.engine.stats_reduce(err, uvs.engine.loop_clock(0.05, 15), full['k_done'])
+    assert torch.allclose(s2, full['stats'], rtol=1e-12, atol=0)
+    discs = plant_ref.place_discs()
+    for t in (7, 131071, 262143 - 1):
+        robot = plant_ref.PinholeUR10(0.05)
+        robot.start(plan.q_start[t])
+        x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 8, 6)
+        nz = noise[:, :, t].cpu().numpy()
+        ref = rmckf_block.run_closed_loop(lambda qq: plant_ref.project(plant_ref.fkine_all(qq)[5], discs), plan.q_start[t], des, nz, 0.05, 15, 0.2, x0,
+                                          kernel_bw=10.0, annealing=True)
+        assert ref['k_done'] == K and rel_err(err[:, :, t].cpu().numpy(), ref['err']) <= 1e-8
+
+
+def test_full_size_config5_properties(uvs):
+    """BASELINE config 5 at its full size (65 536 trials x 299 steps, (m, n) = (32, 7), per-trial records): partition invariance and
+    duplicates bit-exact, fused statistics = statistics kernel, sampled trials against the block oracle."""
+    import torch
+    from oracle import rmckf_block
+    T, K, M, N = 65536, 299, 32, 7
+    lin = uvs.LinearPlant.random(M, N, seed=2)
+    rng = np.random.default_rng(5)
+    q_goal = lin.q0 + rng.uniform(-0.3, 0.3, N)
+    des = lin.features(q_goal)
+    q0_host = q_goal + np.random.default_rng(12345).uniform(-0.15, 0.15, (T, N))
+    x0_row = (lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel()
+    seeds = 123456 + np.arange(T)
+    noise = uvs.noise_device.generate(uvs.NoiseType.ALPHA_STABLE, dict(alpha=1.5, beta=0, gamma=1, delta=0), seeds, M, K, layout='ktc', device='cuda')
+    q0 = torch.as_tensor(q0_host, device='cuda')
+    x0 = torch.as_tensor(np.tile(x0_row, (T, 1)), device='cuda')
+    noise[:, T - 1, :] = noise[:, 4242, :]
+    q0[T - 1] = q0[4242]
+    fp = uvs.engine.make_params(M, N, 'GMCKF', 10, False, 0.05, 15, 0.2, des, False, 0)
+    full = uvs.engine.closed_loop(fp, lin.to_struct(), q0, noise, x0, want=('err',), layout='ktc')
+    err = full['err']                                                        # [step][trial][row]
+    assert int(full['status'].sum()) == 0 and bool((full['k_done'] == K).all())
+    assert torch.equal(err[:, T - 1], err[:, 4242]) and torch.equal(full['stats'][T - 1], full['stats'][4242])
+    lo, hi = 40000, 40000 + 4096 + 5                                         # ragged: the last wavefront of the slice takes the plain store path
+    part = uvs.engine.closed_loop(fp, lin.to_struct(), q0[lo:hi].contiguous(), noise[:, lo:hi].contiguous(), x0[lo:hi].contiguous(), want=('err',), layout='ktc')
+    assert torch.equal(part['err'], err[:, lo:hi]) and torch.equal(part['stats'], full['stats'][lo:hi])
+    s2 = uvs.engine.stats_reduce(err, uvs.engine.loop_clock(0.05, 15), full['k_done'], layout='ktc')
+    assert torch.allclose(s2, full['stats'], rtol=1e-12, atol=0)
+    for t in (3, 40001, 65534):
+        ref = rmckf_block.run_closed_loop(lin.features, q0_host[t], des, noise[:, t].cpu().numpy(), 0.05, 15, 0.2, x0_row, initial_guess=False)
+        assert ref['k_done'] == K and rel_err(err[:, t].cpu().numpy(), ref['err']) <= 1e-8
