@@ -559,9 +559,6 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
 #endif
 
-#ifdef UVS_MCKF_COUNT
-    int dbg_steps = 0, dbg_lanes = 0, dbg_passes = 0;
-#endif
     for (int k = 0; k < K; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         UVS_STAMP(5);
@@ -781,9 +778,6 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
             int it = 1;
             bool more = alive && !fpi.skip && (fpi.num > thr2 * fpi.den);        // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
-#ifdef UVS_MCKF_COUNT
-            dbg_steps += __any(more) ? 1 : 0; dbg_lanes += more ? 1 : 0;
-#endif
             if (__any(more)) {
                 const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
                 bool skip2 = false;
@@ -807,9 +801,6 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                     }
                 }
                 while (__any(more)) {
-#ifdef UVS_MCKF_COUNT
-                    dbg_passes += 1;
-#endif
                     double kn[R][N], num2 = 0.0, den2 = 0.0;
                     bool bad2 = false;
                     if (more) {
@@ -977,10 +968,6 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
     for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
     if (!valid) return;
-#ifdef UVS_MCKF_COUNT
-    if (A.stats) { A.stats[3 * trial] = dbg_steps; A.stats[3 * trial + 1] = dbg_lanes; A.stats[3 * trial + 2] = dbg_passes; }
-    if (A.stats) return;
-#endif
     if (sub == 0) {
         if (A.stats) {
 #pragma unroll
