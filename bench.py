@@ -178,13 +178,17 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
     NV = uvs_amd._lib.NULL_VIEW
     flat = uvs_amd._lib.View(x0.data_ptr(), x0.stride(0), 0, x0.stride(1))
     out = {}
-    for name, cmd, b_alg in (('estimator_and_control_law', True, 8 * (2 * M + 2 * N + M * N)), ('estimator_only', False, 8 * (2 * M + N + M * N))):
+    for name, cmd, b_alg, lay in (('estimator_and_control_law', True, 8 * (2 * M + 2 * N + M * N), 'kct'), ('estimator_only', False, 8 * (2 * M + N + M * N), 'kct'),
+                                  ('estimator_only_records', False, 8 * (2 * M + N + M * N), 'ktc')):
+        if lay == 'ktc':                                          # the same streams as per-trial records ([step][trial][component]); same buffers
+            f, dq = f.permute(0, 2, 1).contiguous(), dq.permute(0, 2, 1).contiguous()
+            x_buf, err_buf = x_buf.view(K, T, M * N), err_buf.view(K, T, M)
         ms = []
         for _ in range(reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = uvs_amd.lib().uvs_rmckf_replay_f64(C.byref(fp), T, engine.stream_view(f, 'kct'), engine.stream_view(dq, 'kct'), flat,
-                                                    engine.stream_view(x_buf, 'kct'), engine.stream_view(err_buf, 'kct'), NV,
+            rc = uvs_amd.lib().uvs_rmckf_replay_f64(C.byref(fp), T, engine.stream_view(f, lay), engine.stream_view(dq, lay), flat,
+                                                    engine.stream_view(x_buf, lay), engine.stream_view(err_buf, lay), NV,
                                                     engine.stream_view(cmd_buf, 'kct') if cmd else NV, status.data_ptr(), k_done.data_ptr(), NV, NV,
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
             uvs_amd._lib.check(rc)
@@ -196,8 +200,11 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
         gbs = updates * b_alg / (avg * 1e-3) / 1e9
         out[name] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s',
                      'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item())}
-    out['kernel'] = 'estimator_and_control_law: replay_tuned_kernel<8,6,GMCKF,2,true,true> (2 lanes/filter); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true> (4 lanes/filter, 2 wavefronts/SIMD)'
-    out['streams'] = 'read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update, [step][component][trial]'
+    out['kernel'] = ('estimator_and_control_law: replay_tuned_kernel<8,6,GMCKF,2,true,true> (2 lanes/filter); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE> '
+                     '(row groups of a filter in the 4 wavefronts of a 64-trial workgroup, 2 wavefronts/SIMD); estimator_only_records: replay_rows_kernel<...,REC> (4 lane groups, '
+                     'LDS-transposed 1 KB stores)')
+    out['streams'] = ('read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update; [step][component][trial], estimator_only_records: per-trial records '
+                      '[step][trial][component]')
     return out
 
 

@@ -92,6 +92,60 @@ def test_estimator_only_replay_matches_reference(uvs, name, lanes):
     assert int(out['status'].sum()) == 0 and np.all(out['k_done'].cpu().numpy() == K)
 
 
+@pytest.mark.parametrize('method', ['GMCKF', 'KF'])
+def test_estimator_only_replay_rowgroup_wavefronts(uvs, method):
+    """Library default for KF / RMCKF without the commanded dq: the four row groups of a filter are the four wavefronts of a 64-trial
+    workgroup.  Same arithmetic as the four-lane-group kernel, so every stream is bit-identical to it: 150 trials (2 workgroups + 22),
+    two trials failing in different row groups at different steps (the earlier step wins)."""
+    g = load_golden({'GMCKF': 'closed_gmckf_a1p5', 'KF': 'closed_kf_a1p5'}[method])
+    K, T = 80, 150
+    rng = np.random.default_rng(12)
+    f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+    f = np.repeat(f_seq[:, :, None], T, axis=2)
+    f[1:, :, 1:] += rng.standard_normal((K, 8, T - 1))
+    f[31, 6, 70] = np.nan                                                      # row group 2 of trial 70 at step 30
+    f[51, 1, 70] = np.inf                                                      # row group 1 of the same trial, later
+    f[41, 3, 149] = np.inf                                                     # row group 3 of the last (ragged) trial at step 40
+    dq = np.repeat(g['dq_prev'][:K, :, None], T, axis=2) * (1.0 + 0.1 * rng.standard_normal((K, 6, T)))
+    x0 = np.tile(g['X'][0], (T, 1)) + rng.standard_normal((T, 48))
+    want = ('x', 'err', 'kappa')
+    a = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=want, final_state=True)
+    b = uvs.engine.replay(_fp(uvs, g, 4, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=want, final_state=True)
+    for key in want + ('x_final', 'p_final', 'status', 'k_done'):
+        assert np.array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), equal_nan=True), key
+    k_done = a['k_done'].cpu().numpy()
+    assert k_done[70] == 30 and k_done[149] == 40 and int((k_done != K).sum()) == 2 and int(a['status'].sum()) == 2
+
+
+@pytest.mark.parametrize('T', [48, 35])
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF', 'MCKF'])
+def test_estimator_only_replay_record_layout(uvs, method, T):
+    """X and err as per-trial records ([step][trial][component]): whole wavefronts (T = 48) take the LDS-transposed 1 KB-store path, a ragged
+    batch (T = 35) the strided one; inputs trial-fastest or records.  Same arithmetic: every stream bit-identical to the trial-fastest run."""
+    g = load_golden({'GMCKF': 'closed_gmckf_a1p5', 'KF': 'closed_kf_a1p5', 'IMCCKF': 'closed_imcckf_a1p5', 'MCKF': 'closed_mckf_a1p5'}[method])
+    K = 60
+    rng = np.random.default_rng(13)
+    f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+    f = np.repeat(f_seq[:, :, None], T, axis=2)
+    f[1:, :, 1:] += rng.standard_normal((K, 8, T - 1))
+    f[21, 2, T - 2] = np.inf                                                   # one trial fails at step 20
+    dq = np.repeat(g['dq_prev'][:K, :, None], T, axis=2) * (1.0 + 0.1 * rng.standard_normal((K, 6, T)))
+    x0 = np.tile(g['X'][0], (T, 1)) + rng.standard_normal((T, 48))
+    fp = _fp(uvs, g, 4, steps=K)
+    ref = uvs.engine.replay(fp, _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err'), final_state=True)
+    for in_layout in ('kct', 'ktc'):
+        fi, di = (f, dq) if in_layout == 'kct' else (f.transpose(0, 2, 1), dq.transpose(0, 2, 1))
+        out = uvs.engine.replay(fp, _cuda(np.ascontiguousarray(fi)), _cuda(np.ascontiguousarray(di)), _cuda(x0), want=('x', 'err'), layout='ktc',
+                                final_state=True, in_layout=in_layout)
+        for key in ('x', 'err'):
+            a = uvs.engine.as_tkc(out[key], 'ktc').cpu().numpy()
+            b = uvs.engine.as_tkc(ref[key], 'kct').cpu().numpy()
+            assert np.array_equal(a, b, equal_nan=True), (key, in_layout)
+        for key in ('x_final', 'p_final', 'status', 'k_done'):
+            assert np.array_equal(out[key].cpu().numpy(), ref[key].cpu().numpy(), equal_nan=True), (key, in_layout)
+    assert int(ref['k_done'][T - 2]) == 20 and int((ref['status'] == 1).sum()) == 1
+
+
 def test_estimator_only_replay_fail_semantics(uvs):
     g = load_golden('closed_gmckf_a1p5')
     K, T, bad = 60, 20, 23

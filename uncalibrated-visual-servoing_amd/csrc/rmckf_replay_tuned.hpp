@@ -235,15 +235,27 @@ UVS_DEV double blocked_sum(double v) {
 // budget, and a second wavefront on the SIMD issues its arithmetic under this one's stores: the replay becomes HBM-bound.
 // EOUT (err stream wanted) is compile-time like XOUT: the prefetched inputs are waited for with an in-order vmcnt that must let every
 // store issued after them stay in flight, and the compiler can only count stores it knows will be issued.
-template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT>
-__global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) {
+//
+// BYWAVE (KF and RMCKF, whose rows share nothing but the finiteness verdict): the L row groups of a filter are the L WAVEFRONTS of a
+// workgroup instead of L lane groups of one wavefront -- lane = trial, wavefront = row group, 64 consecutive trials per workgroup.
+// Same registers, same arithmetic, no cross-lane traffic at all, and every load and store of a wavefront covers 64 consecutive trials:
+// 512 contiguous bytes in the trial-fastest layout instead of four 128-byte segments.  The verdicts meet in LDS once, after the loop.
+//
+// REC (lane groups only): the X and err streams are per-trial records ([step][trial][component]: comp_stride 1, trial_stride M N resp. M).
+// The TPW trials of a wavefront are then ONE contiguous block per step (TPW M N doubles of X, TPW M of err): the finished rows are
+// transposed through a wavefront-private LDS buffer and leave as whole 1 KB stores (64 lanes x 16 B), issued from the hook points of the
+// next step's first row.
+template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT, bool BYWAVE = false, bool REC = false>
+__global__ __launch_bounds__(BYWAVE ? 64 * L : 64, 2) void replay_rows_kernel(const ReplayArgs A) {
     static_assert((L == 2 || L == 4) && M % L == 0, "rows kernel: 2 or 4 lanes per filter");
-    constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;
+    static_assert(!(REC && BYWAVE) && (!REC || (XOUT && EOUT)), "record path: lane groups, X and err both wanted");
+    static_assert(!BYWAVE || METHOD == UVS_METHOD_GMCKF || METHOD == UVS_METHOD_KF, "row groups in separate wavefronts: independent rows only");
+    constexpr int R = M / L, NP = Sym<N>::NP, TPW = BYWAVE ? 64 : 64 / L;
     // Lane -> (trial, sub) is blocked, not interleaved: lanes [sub * TPW, (sub + 1) * TPW) hold row group `sub` of TPW consecutive
     // trials, so the four lanes of every quad store to adjacent addresses.  With the interleaved mapping of the least-squares kernels
     // (partner lanes adjacent, for DPP) a quad scatters over L component rows and the same stores cost 3x as much here.
     const unsigned lane = threadIdx.x;
-    const int sub = (int)(lane / TPW);
+    const int sub = BYWAVE ? __builtin_amdgcn_readfirstlane((int)(lane >> 6)) : (int)(lane / TPW);
     const long long wave_first = (long long)blockIdx.x * TPW;
     const unsigned tl = lane % TPW;
     const bool valid = wave_first + tl < A.T;
@@ -253,15 +265,28 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
 
     const double *pf = A.f.at(trial, 1, sub);
     const double *pd = A.dq.at(trial, 1, 0);
-    double *px = (XOUT && A.x_out.p) ? A.x_out.at(trial, 0, sub * N) : nullptr;
-    double *pe = (EOUT && A.err_out.p) ? A.err_out.at(trial, 0, sub) : nullptr;
+    double *px = (XOUT && A.x_out.p) ? (REC ? A.x_out.at(wave_first, 0, 2 * lane) : A.x_out.at(trial, 0, sub * N)) : nullptr;
+    double *pe = (EOUT && A.err_out.p) ? (REC ? A.err_out.at(wave_first, 0, 2 * lane) : A.err_out.at(trial, 0, sub)) : nullptr;
     double *pk = A.kappa_out.p ? A.kappa_out.at(trial, 0, sub) : nullptr;
     const bool on_kappa = A.kappa_out.p != nullptr;
+    // record path: LDS copies of the wavefront's block, records padded by one double against bank conflicts; src_x[i]: where the pair of
+    // doubles this lane stores with the i-th 1 KB store lives (a pair never straddles two records: M N and M are even)
+    constexpr int XREC = M * N, XRECP = XREC + 1, EREC = M, ERECP = EREC + 1, XS = TPW * XREC / 128, ES = TPW * EREC / 128;
+    static_assert(!REC || ((TPW * XREC) % 128 == 0 && (TPW * EREC) % 128 == 0 && XS + ES <= N + 1), "record path: whole 1 KB stores, one per hook point of a row");
+    __shared__ double ltx[REC ? TPW * XRECP : 1], lte[REC ? TPW * ERECP : 1];
+    int src_x[REC ? XS : 1], src_e[REC ? ES : 1];
+    if constexpr (REC) {
+#pragma unroll
+        for (int i = 0; i < XS; ++i) { const int d = 128 * i + 2 * (int)lane; src_x[i] = (d / XREC) * XRECP + d % XREC; }
+#pragma unroll
+        for (int i = 0; i < ES; ++i) { const int d = 128 * i + 2 * (int)lane; src_e[i] = (d / EREC) * ERECP + d % EREC; }
+    }
 
     double f_prev[R], des[R], f_next[R], h_next[N], x[R][N], p[R][NP];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        des[r] = pick_sub<L>(&fp.desired[r * L], sub);
+        if constexpr (BYWAVE) des[r] = fp.desired[r * L + sub];
+        else des[r] = pick_sub<L>(&fp.desired[r * L], sub);
         f_prev[r] = *A.f.at(trial, 0, r * L + sub);
         f_next[r] = 0.0;
 #pragma unroll
@@ -283,7 +308,13 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
 
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true, flagged = false;                          // flagged (MCKF): a step needs more than the first fixed-point pass
-    for (int k = 0; k < K; ++k) {
+    // The stores of a step are software-pipelined behind the arithmetic (rmckf_row's hook points): while row r is updated, the X row and the
+    // error of row r - 1 -- finished, and untouched until the next step -- go out one store at a time; row R - 1 of a step goes out
+    // during row 0 of the next step, and after the last step on its own.  `step` is the loop body, FIRST = nothing pending yet (the first
+    // step is peeled instead of branching around the stores: the compiler's in-order vmcnt for the prefetched inputs must see every store).
+    double err_last = 0.0;
+    auto step = [&](int k, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         double f[R], dq[N];
 #pragma unroll
         for (int r = 0; r < R; ++r) f[r] = f_next[r];
@@ -328,22 +359,57 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
             fpi.skip = blocked_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
             fpi.unsure = blocked_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0;
         }
-        double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double zi = f[r] - f_prev[r];
             f_prev[r] = f[r];
             err[r] = f[r] - des[r];
-            rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
-            if constexpr (XOUT) {
-                double *pcx = pxr;
+            // pending: row r - 1 of this step, or row R - 1 of the previous one
+            const int rr = (r + R - 1) % R;
+            const double (&xs)[N] = x[rr];
+            const double es = (r == 0) ? err_last : err[rr];
+            double *pxs = px ? px + (long long)rr * L * N * A.x_out.sc - (r == 0 ? A.x_out.sk : 0) : nullptr;
+            double *pes = pe ? pe + (long long)rr * L * A.err_out.sc - (r == 0 ? A.err_out.sk : 0) : nullptr;
+            auto hook = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (REC) {
+                    if (r == 0) {                                  // the previous step's block: LDS -> one 1 KB store per hook point
+                        if constexpr (!FIRST) {
+                            if constexpr (i < XS) {
+                                const double *src = &ltx[src_x[i]];
+                                double2 v;
+                                v.x = src[0];
+                                v.y = src[1];
+                                *reinterpret_cast<double2 *>(px + 128 * i - A.x_out.sk) = v;
+                            } else if constexpr (i < XS + ES) {
+                                const double *src = &lte[src_e[i - XS]];
+                                double2 v;
+                                v.x = src[0];
+                                v.y = src[1];
+                                *reinterpret_cast<double2 *>(pe + 128 * (i - XS) - A.err_out.sk) = v;
+                            }
+                        }
+                    } else {                                       // row r - 1 of this step into the LDS block
+                        if constexpr (i < N) ltx[tl * XRECP + (rr * L + sub) * N + i] = xs[i];
+                        else lte[tl * ERECP + rr * L + sub] = es;
+                    }
+                } else {
+                    if constexpr (FIRST) { if (r == 0) return; }
+                    if constexpr (i < N) { if constexpr (XOUT) pxs[i * A.x_out.sc] = xs[i]; }
+                    else { if constexpr (EOUT) *pes = es; }
+                }
+            };
+            rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi, hook);
+        }
+        err_last = err[R - 1];
+        if constexpr (REC) {                                       // the last row of this step into the LDS block
 #pragma unroll
-                for (int j = 0; j < N; ++j) { *pcx = x[r][j]; pcx += A.x_out.sc; }
-                pxr += L * N * A.x_out.sc;
-            }
+            for (int j = 0; j < N; ++j) ltx[tl * XRECP + ((R - 1) * L + sub) * N + j] = x[R - 1][j];
+            lte[tl * ERECP + (R - 1) * L + sub] = err_last;
         }
         if constexpr (XOUT) px += A.x_out.sk;
-        chk = blocked_sum<L>(chk);
+        if constexpr (EOUT) pe += A.err_out.sk;
+        if constexpr (!BYWAVE) chk = blocked_sum<L>(chk);
         if (alive && !(chk == 0.0)) {
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -354,22 +420,51 @@ __global__ __launch_bounds__(64, 2) void replay_rows_kernel(const ReplayArgs A) 
             fpi.den = blocked_sum<L>(fpi.den);
             flagged |= alive && fpi_needs_more(fpi, fp);
         }
-        // no early exit when every trial of the wavefront has failed: a path that skips the err stores would make the compiler's
-        // in-order vmcnt for the prefetched inputs count only the X stores and wait for the rest, every step
-        if constexpr (EOUT) {
-            double *po = pe;
-#pragma unroll
-            for (int r = 0; r < R; ++r) { *po = err[r]; po += L * A.err_out.sc; }
-            pe += A.err_out.sk;
-        }
         if (on_kappa) {
             double *po = pk;
 #pragma unroll
             for (int r = 0; r < R; ++r) { *po = kap[r]; po += L * A.kappa_out.sc; }
             pk += A.kappa_out.sk;
         }
+    };
+    if (K > 0) {
+        step(0, std::true_type{});
+        for (int k = 1; k < K; ++k) step(k, std::false_type{});
+        if constexpr (REC) {                                       // the block of the last step
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                const double *src = &ltx[src_x[i]];
+                double2 v;
+                v.x = src[0];
+                v.y = src[1];
+                *reinterpret_cast<double2 *>(px + 128 * i - A.x_out.sk) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < ES; ++i) {
+                const double *src = &lte[src_e[i]];
+                double2 v;
+                v.x = src[0];
+                v.y = src[1];
+                *reinterpret_cast<double2 *>(pe + 128 * i - A.err_out.sk) = v;
+            }
+        } else {                                                   // row R - 1 of the last step
+            if constexpr (XOUT) {
+                double *po = px + (long long)(R - 1) * L * N * A.x_out.sc - A.x_out.sk;
+#pragma unroll
+                for (int j = 0; j < N; ++j) po[j * A.x_out.sc] = x[R - 1][j];
+            }
+            if constexpr (EOUT) *(pe + (long long)(R - 1) * L * A.err_out.sc - A.err_out.sk) = err_last;
+        }
     }
 
+    if constexpr (BYWAVE) {                                       // a trial fails at the first step at which any of its row groups turned non-finite
+        __shared__ int lk[L][64];
+        lk[sub][tl] = k_done;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < L; ++g) k_done = lk[g][tl] < k_done ? lk[g][tl] : k_done;
+        status = (k_done < K) ? UVS_STATUS_FAIL : UVS_STATUS_SUCCESS;
+    }
     if (!valid) return;
     if (sub == 0) {
         if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;

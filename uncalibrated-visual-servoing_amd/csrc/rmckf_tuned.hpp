@@ -17,6 +17,7 @@
 //   * divisions / roots / sincos come from rmckf_math.hpp (v_rcp/v_rsq + Newton steps, bounded-argument sincos).
 // With the trial-fastest layout ([step][component][trial]) each wavefront store covers 512 / L contiguous bytes per owned row.
 #pragma once
+#include <type_traits>
 #include "rmckf_device.hpp"
 #include "rmckf_math.hpp"
 
@@ -265,11 +266,27 @@ UVS_DEV void mckf_commit_row(double (&x)[N], double (&pp)[Sym<N>::NP], const dou
     }
 }
 
-template <int N, int METHOD>
+// Hook: a kernel may hand the row update work that is independent of it -- the streaming stores of values finished earlier -- to be
+// issued at N + 1 fixed points spread over the row's arithmetic (hook(integral_constant<int, i>), i = 0..N), each pinned between
+// scheduling fences.  A wavefront that issues its stores in one burst stalls at the full store queue while the SIMD has nothing else to run;
+// one store every ~20 arithmetic instructions keeps both busy.  NoHook (every other kernel): nothing is emitted, the schedule is hipcc's.
+struct NoHook {};
+template <int I, typename Hook>
+UVS_DEV void row_hook(Hook &hook) {
+    if constexpr (!std::is_same<Hook, NoHook>::value) {
+        __builtin_amdgcn_sched_barrier(0);
+        hook(std::integral_constant<int, I>{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int N, int METHOD, typename Hook>
 UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
-                       double reg, double &kap, double &chk, FpiProbe &fpi) {
+                       double reg, double &kap, double &chk, FpiProbe &fpi, Hook &hook) {
+    static_assert(std::is_same<Hook, NoHook>::value || N == 6, "hook points are placed for n = 6");
     double g[N];
     double pred = 0.0;
+    row_hook<0>(hook);
 #pragma unroll
     for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
     const double nu = zi - pred;                                 // innovation (experiment.py:274)
@@ -285,8 +302,11 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 #pragma unroll
         for (int j = 1; j < N; ++j) acc = fma(pb[Sym<N>::at(l, j)], dq[j], acc);
         g[l] = acc;
+        if (l == 1) row_hook<1>(hook);
+        if (l == 3) row_hook<2>(hook);
     }
 #endif
+    row_hook<3>(hook);
     double a = 0.0;
 #pragma unroll
     for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
@@ -320,6 +340,7 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         kap = 1.0;
         gamma = fast_rcp(a + 1.0);
     }
+    row_hook<4>(hook);
     const double step = gamma * nu;
     const double beta = gamma * (2.0 - gamma * (a + 1.0));
 #pragma unroll
@@ -327,16 +348,25 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         x[j] = fma(g[j], step, x[j]);                            // X + K (Z - H X) (experiment.py:291)
         chk = fma(x[j], 0.0, chk);
     }
+    row_hook<5>(hook);
 #ifndef UVS_ABLATE_ROWS
 #pragma unroll
     for (int l = 0; l < N; ++l) {                                // Joseph update with R = 1: P -= beta g g^T
         const double w = beta * g[l];
 #pragma unroll
         for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
+        if (l == 1) row_hook<6>(hook);
     }
 #else
     pb[0] = fma(-beta, g[0], pb[0]);
 #endif
+}
+
+template <int N, int METHOD>
+UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
+                       double reg, double &kap, double &chk, FpiProbe &fpi) {
+    NoHook none;
+    rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, reg, kap, chk, fpi, none);
 }
 
 template <int N, int METHOD>

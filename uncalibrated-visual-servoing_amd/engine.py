@@ -113,8 +113,10 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     return out
 
 
-def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', final_state=False):
-    """Open-loop replay.  ``f``: stream tensor with K+1 steps, ``dq``: K steps, ``x0``: (T, m*n)."""
+def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', final_state=False, in_layout=None):
+    """Open-loop replay.  ``f``: stream tensor with K+1 steps, ``dq``: K steps, ``x0``: (T, m*n).  ``layout``: physical layout of the
+    output streams and, unless ``in_layout`` says otherwise, of ``f`` / ``dq``."""
+    in_layout = in_layout or layout
     torch = _torch()
     T, K, m, n = x0.shape[0], fp.steps, fp.m, fp.n
     dev = x0.device
@@ -127,7 +129,7 @@ def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', fin
     out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
     flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
     rc = _lib.lib().uvs_rmckf_replay_f64(
-        C.byref(fp), T, stream_view(f, layout), stream_view(dq, layout), flat(x0),
+        C.byref(fp), T, stream_view(f, in_layout), stream_view(dq, in_layout), flat(x0),
         stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['kappa'], layout),
         stream_view(out['dqcmd'], layout), out['status'].data_ptr(), out['k_done'].data_ptr(),
         flat(out['x_final']), flat(out['p_final']), _stream())
