@@ -138,6 +138,10 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
  *   x0       [T][1][m*n]  in
  *   x_out    [T][K][m*n], err_out [T][K][m], kappa_out [T][K][m], dqcmd_out [T][K][n]  out (NULL to skip)
  *   status   [T] int32, k_done [T] int32  out   (status is REQUIRED when dqcmd_out is requested: same two-pass scheme as the closed loop)
+ * Without dqcmd_out nothing couples a filter's rows and (8,6) runs the estimator-only kernel.  Fastest store paths, chosen from the views
+ * (any other strides work, slower): x_out and err_out both as per-trial records (comp_stride 1, trial_stride m*n resp. m, i.e.
+ * [step][trial][component]; T a multiple of 16, 16-byte aligned): whole 1 KB stores; trial-fastest ([step][component][trial]):
+ * 512-byte stores for KF / RMCKF at lanes_per_filter = 0.
  */
 int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs_view dq, uvs_view x0,
                          uvs_view x_out, uvs_view err_out, uvs_view kappa_out, uvs_view dqcmd_out,
