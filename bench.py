@@ -200,7 +200,7 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
         gbs = updates * b_alg / (avg * 1e-3) / 1e9
         out[name] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s',
                      'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item())}
-    out['kernel'] = ('estimator_and_control_law: replay_tuned_kernel<8,6,GMCKF,2,true,true> (2 lanes/filter); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE> '
+    out['kernel'] = ('estimator_and_control_law: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE,CW=2> (4 estimator + 2 control-law wavefronts per 64 trials); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE> '
                      '(row groups of a filter in the 4 wavefronts of a 64-trial workgroup, 2 wavefronts/SIMD); estimator_only_records: replay_rows_kernel<...,REC> (4 lane groups, '
                      'LDS-transposed 1 KB stores)')
     out['streams'] = ('read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update; [step][component][trial], estimator_only_records: per-trial records '

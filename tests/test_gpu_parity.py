@@ -117,6 +117,36 @@ def test_estimator_only_replay_rowgroup_wavefronts(uvs, method):
     assert k_done[70] == 30 and k_done[149] == 40 and int((k_done != K).sum()) == 2 and int(a['status'].sum()) == 2
 
 
+@pytest.mark.parametrize('method', ['GMCKF', 'KF'])
+def test_replay_control_wavefronts(uvs, method):
+    """Library default for KF / RMCKF with the commanded dq: four estimator wavefronts (row groups) + two control-law wavefronts per 64
+    trials (normal equations + refinement).  150 trials (2 workgroups + 22), odd and even horizons, one failing trial: estimator streams
+    as the two-lane kernel's, commanded dq within 1e-9 of its Householder solve, status / k_done equal."""
+    g = load_golden({'GMCKF': 'closed_gmckf_a1p5', 'KF': 'closed_kf_a1p5'}[method])
+    T = 150
+    for K in (80, 81, 1):
+        rng = np.random.default_rng(14)
+        f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+        f = np.repeat(f_seq[:, :, None], T, axis=2)
+        f[1:, :, 1:] += rng.standard_normal((K, 8, T - 1))
+        if K > 40:
+            f[41, 3, 149] = np.inf                                             # the last (ragged) trial fails at step 40
+        dq = np.repeat(g['dq_prev'][:K, :, None], T, axis=2) * (1.0 + 0.1 * rng.standard_normal((K, 6, T)))
+        x0 = np.tile(g['X'][0], (T, 1)) + rng.standard_normal((T, 48))
+        want = ('x', 'err', 'kappa', 'dqcmd')
+        a = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=want, final_state=True)
+        b = uvs.engine.replay(_fp(uvs, g, 2, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=want, final_state=True)
+        good = np.arange(T) != 149
+        for key in ('x', 'err', 'kappa'):
+            assert rel_err(a[key].cpu().numpy()[:, :, good], b[key].cpu().numpy()[:, :, good]) <= 1e-12, (key, K)
+        assert rel_err(a['dqcmd'].cpu().numpy()[:, :, good], b['dqcmd'].cpu().numpy()[:, :, good]) <= 1e-9, K
+        for key in ('x_final', 'p_final'):
+            assert rel_err(a[key].cpu().numpy()[good], b[key].cpu().numpy()[good]) <= 1e-12, (key, K)
+        assert np.array_equal(a['status'].cpu().numpy(), b['status'].cpu().numpy()) and np.array_equal(a['k_done'].cpu().numpy(), b['k_done'].cpu().numpy())
+        if K > 40:
+            assert int(a['k_done'][149]) == 40 and int(a['status'][149]) == 1 and int(a['status'].sum()) == 1
+
+
 @pytest.mark.parametrize('T', [48, 35])
 @pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF', 'MCKF'])
 def test_estimator_only_replay_record_layout(uvs, method, T):

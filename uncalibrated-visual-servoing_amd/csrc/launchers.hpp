@@ -54,6 +54,7 @@ bool replay_careful_a(int m, int n, int64_t T, hipStream_t s, const uvs::ReplayA
 bool replay_careful_b(int m, int n, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 // tuned replay (rmckf_replay_tuned.hpp): two lanes per filter with the control law, four lanes per filter for the estimator alone
 bool replay_tuned(int m, int n, int method, bool xo, bool cmd, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+bool replay_rows_cmd(int m, int n, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool replay_rows(int m, int n, int method, bool bywave, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 // everything else
 void stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *stats, hipStream_t s);

@@ -220,6 +220,47 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
 
 namespace uvs {
 
+// One trial per lane, everything in registers: sol = pinv(J) y by the normal equations with one refinement step (the solver of
+// rmckf_split.hpp, which streams J from LDS because its wavefront also carries covariance blocks; a control wavefront of the replay
+// carries nothing else).  Split in two halves so that a workgroup barrier can sit between them.
+template <int M, int N>
+UVS_DEV void normal_eq_gram(const double (&x)[M][N], const double (&y)[M], double (&G)[Sym<N>::NP], double (&b)[N]) {
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+#pragma unroll
+        for (int j = l; j < N; ++j) {
+            double acc = x[0][l] * x[0][j];
+#pragma unroll
+            for (int i = 1; i < M; ++i) acc = fma(x[i][l], x[i][j], acc);
+            G[Sym<N>::at(l, j)] = acc;
+        }
+        double acc = x[0][l] * y[0];
+#pragma unroll
+        for (int i = 1; i < M; ++i) acc = fma(x[i][l], y[i], acc);
+        b[l] = acc;
+    }
+}
+template <int M, int N>
+UVS_DEV bool normal_eq_finish(const double (&x)[M][N], const double (&y)[M], double (&G)[Sym<N>::NP], double (&b)[N], double (&sol)[N]) {
+    double rs[N], c[N];
+    const bool suspect = chol_factor<N>(G, rs);
+    chol_solve_inplace<N>(G, rs, b);                             // s0
+#pragma unroll
+    for (int j = 0; j < N; ++j) c[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {                                // c = J^T (y - J s0)
+        double ri = y[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) ri = fma(-x[i][j], b[j], ri);
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[j] = fma(x[i][j], ri, c[j]);
+    }
+    chol_solve_inplace<N>(G, rs, c);
+#pragma unroll
+    for (int j = 0; j < N; ++j) sol[j] = b[j] + c[j];
+    return suspect;
+}
+
 // Sum over the L lanes lane, lane ^ (64 / L), ... that hold one filter under the blocked mapping; every lane gets the bit-identical total
 // (butterfly through the LDS crossbar, ds_bpermute; used once or twice per step).
 template <int L>
@@ -245,9 +286,17 @@ UVS_DEV double blocked_sum(double v) {
 // The TPW trials of a wavefront are then ONE contiguous block per step (TPW M N doubles of X, TPW M of err): the finished rows are
 // transposed through a wavefront-private LDS buffer and leave as whole 1 KB stores (64 lanes x 16 B), issued from the hook points of the
 // next step's first row.
-template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT, bool BYWAVE = false, bool REC = false>
-__global__ __launch_bounds__(BYWAVE ? 64 * L : 64, 2) void replay_rows_kernel(const ReplayArgs A) {
+//
+// CW = 2 (BYWAVE only; the commanded dq is wanted): two more wavefronts per workgroup run the control law dq = -gain pinv(X_k)(kappa o err)
+// with one trial per lane.  In a replay nothing waits for that result -- the next regressor comes from the recorded stream -- so the
+// estimator wavefronts only drop X_k, kappa o err and their finiteness probe into a double-buffered LDS block and meet the control
+// wavefronts at one barrier per step; control wavefront c takes the steps k = c (mod 2) and has two barrier intervals for each (Gram
+// matrix in the first, Cholesky + solve + refinement + stores in the second).  Normal equations: ill-conditioned Jacobians are marked
+// for the careful second pass exactly as in the role-split closed-loop kernel.
+template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT, bool BYWAVE = false, bool REC = false, int CW = 0>
+__global__ __launch_bounds__(BYWAVE ? 64 * (L + CW) : 64, 2) void replay_rows_kernel(const ReplayArgs A) {
     static_assert((L == 2 || L == 4) && M % L == 0, "rows kernel: 2 or 4 lanes per filter");
+    static_assert(CW == 0 || (CW == 2 && BYWAVE), "control wavefronts: with the row groups in wavefronts");
     static_assert(!(REC && BYWAVE) && (!REC || (XOUT && EOUT)), "record path: lane groups, X and err both wanted");
     static_assert(!BYWAVE || METHOD == UVS_METHOD_GMCKF || METHOD == UVS_METHOD_KF, "row groups in separate wavefronts: independent rows only");
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = BYWAVE ? 64 : 64 / L;
@@ -262,6 +311,46 @@ __global__ __launch_bounds__(BYWAVE ? 64 * L : 64, 2) void replay_rows_kernel(co
     const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
+
+    constexpr int CV = M * N + M;                                  // values an estimator step hands to the control law: X_k, kappa o err
+    __shared__ double lcb[CW ? 2 : 1][CW ? CV : 1][64];
+    __shared__ double lcc[CW ? 2 : 1][CW ? L : 1][64];             // finiteness probes of the row groups
+    __shared__ int lcflag[64];
+    if constexpr (CW > 0) {
+        if (lane < 64) lcflag[lane] = 0;
+        if (sub >= L) {                                            // ---- control wavefront c = sub - L: steps k = c (mod 2)
+            const int c = sub - L;
+            double xs[M][N], ys[M], G[NP], b[N];
+            bool ok = false;
+            __syncthreads();                                       // lcflag cleared
+            for (int k = 0; k <= K; ++k) {
+                if (k < K) __syncthreads();                        // barrier k: the block of step k is complete
+                if (k < K && (k & 1) == c) {
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) xs[i][j] = lcb[k & 1][i * N + j][tl];
+                        ys[i] = lcb[k & 1][M * N + i][tl];
+                    }
+                    double probe = 0.0;
+#pragma unroll
+                    for (int g = 0; g < L; ++g) probe += lcc[k & 1][g][tl];
+                    ok = probe == 0.0;
+                    normal_eq_gram<M, N>(xs, ys, G, b);
+                } else if (k >= 1 && ((k - 1) & 1) == c) {
+                    double sol[N];
+                    const bool suspect = normal_eq_finish<M, N>(xs, ys, G, b, sol);
+                    if (ok && suspect) lcflag[tl] = 1;             // ill-conditioned Jacobian: the careful second pass redoes this trial
+                    double *po = A.dqcmd_out.at(trial, k - 1, 0);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) po[j * A.dqcmd_out.sc] = -fp.gain * sol[j];      // experiment.py:312
+                }
+            }
+            __syncthreads();                                       // the estimator wavefronts' verdict exchange
+            return;
+        }
+        __syncthreads();                                           // lcflag cleared
+    }
 
     const double *pf = A.f.at(trial, 1, sub);
     const double *pd = A.dq.at(trial, 1, 0);
@@ -402,6 +491,16 @@ __global__ __launch_bounds__(BYWAVE ? 64 * L : 64, 2) void replay_rows_kernel(co
             rmckf_row<N, METHOD>(x[r], p[r], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi, hook);
         }
         err_last = err[R - 1];
+        if constexpr (CW > 0) {                                    // hand X_k, kappa o err and the probe to the control wavefronts
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) lcb[k & 1][(r * L + sub) * N + j][tl] = x[r][j];
+                lcb[k & 1][M * N + r * L + sub][tl] = kap[r] * err[r];
+            }
+            lcc[k & 1][sub][tl] = chk;
+            __syncthreads();                                       // barrier k
+        }
         if constexpr (REC) {                                       // the last row of this step into the LDS block
 #pragma unroll
             for (int j = 0; j < N; ++j) ltx[tl * XRECP + ((R - 1) * L + sub) * N + j] = x[R - 1][j];
@@ -464,6 +563,7 @@ __global__ __launch_bounds__(BYWAVE ? 64 * L : 64, 2) void replay_rows_kernel(co
 #pragma unroll
         for (int g = 0; g < L; ++g) k_done = lk[g][tl] < k_done ? lk[g][tl] : k_done;
         status = (k_done < K) ? UVS_STATUS_FAIL : UVS_STATUS_SUCCESS;
+        if constexpr (CW > 0) flagged = lcflag[tl] != 0;
     }
     if (!valid) return;
     if (sub == 0) {

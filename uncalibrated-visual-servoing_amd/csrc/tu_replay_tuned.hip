@@ -49,6 +49,15 @@ bool uvs_launch::replay_tuned(int m, int n, int method, bool xo, bool cmd, int64
 // Three mappings of the same arithmetic.  Record streams (X and err both [step][trial][component], whole wavefronts of 16 trials, 16-byte
 // aligned): lane groups + LDS transposition, 1 KB stores.  Otherwise KF / RMCKF at lanes_per_filter = 0: the four row groups of a filter in
 // the four wavefronts of a workgroup of 64 trials (512-byte stores in the trial-fastest layout).  Otherwise four lane groups of one wavefront.
+// Estimator in four row-group wavefronts + control law in two more (KF / RMCKF, X, err and the commanded dq all wanted).
+bool uvs_launch::replay_rows_cmd(int m, int n, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A) {
+    if (m != 8 || n != 6 || !(method == UVS_METHOD_GMCKF || method == UVS_METHOD_KF)) return false;
+    const dim3 g((unsigned)((T + 63) / 64));
+    if (method == UVS_METHOD_GMCKF) hipLaunchKernelGGL((uvs::replay_rows_kernel<8, 6, 4, UVS_METHOD_GMCKF, true, true, true, false, 2>), g, dim3(384), 0, s, A);
+    else hipLaunchKernelGGL((uvs::replay_rows_kernel<8, 6, 4, UVS_METHOD_KF, true, true, true, false, 2>), g, dim3(384), 0, s, A);
+    return true;
+}
+
 bool uvs_launch::replay_rows(int m, int n, int method, bool bywave, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A) {
     if (m != 8 || n != 6) return false;
     const bool rec = xo && eo && T % 16 == 0 && A.x_out.sc == 1 && A.x_out.st == 48 && A.err_out.sc == 1 && A.err_out.st == 8 &&

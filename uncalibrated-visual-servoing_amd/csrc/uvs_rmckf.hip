@@ -145,6 +145,9 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     // registers, two wavefronts per SIMD (library default, or lanes_per_filter = 4)
     if (tuned_method && !dqcmd_out.base && (fp->lanes_per_filter == 0 || fp->lanes_per_filter == 4))
         launched = replay_rows(fp->m, fp->n, fp->method, fp->lanes_per_filter == 0, x_out.base != nullptr, err_out.base != nullptr, T, s, A);
+    // with the commanded dq (library default lanes, KF / RMCKF, X and err wanted too): the same estimator wavefronts + control wavefronts
+    if (!launched && tuned_method && dqcmd_out.base && x_out.base && err_out.base && fp->lanes_per_filter == 0)
+        launched = replay_rows_cmd(fp->m, fp->n, fp->method, T, s, A);
     if (!launched && tuned_ok) launched = replay_tuned(fp->m, fp->n, fp->method, x_out.base != nullptr, dqcmd_out.base != nullptr, T, s, A);
     if (!launched) launched = replay_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || replay_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
