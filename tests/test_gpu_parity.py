@@ -147,6 +147,30 @@ def test_replay_control_wavefronts(uvs, method):
             assert int(a['k_done'][149]) == 40 and int(a['status'][149]) == 1 and int(a['status'].sum()) == 1
 
 
+def test_replay_default_kernels_edge_sizes(uvs):
+    """The library-default replay mappings (row-group wavefronts, + control wavefronts with the commanded dq, record path) at the edges:
+    one trial, one short of / exactly / one past a 64-trial workgroup, horizons of 1, 2 and 3 steps -- against the two-lane kernel."""
+    g = load_golden('closed_gmckf_a1p5')
+    rng = np.random.default_rng(15)
+    for T in (1, 16, 63, 64, 65, 129):
+        for K in (1, 2, 3, 17):
+            f_seq = np.vstack([g['f_init'][None], g['f']])[:K + 1]
+            f = np.repeat(f_seq[:, :, None], T, axis=2) + rng.standard_normal((K + 1, 8, T))
+            dq = np.repeat(g['dq_prev'][:K, :, None], T, axis=2) * (1.0 + 0.1 * rng.standard_normal((K, 6, T)))
+            x0 = np.tile(g['X'][0], (T, 1)) + rng.standard_normal((T, 48))
+            ref = uvs.engine.replay(_fp(uvs, g, 2, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err', 'dqcmd'), final_state=True)
+            a = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err', 'dqcmd'), final_state=True)
+            b = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err'), final_state=True)
+            c = uvs.engine.replay(_fp(uvs, g, 0, steps=K), _cuda(f), _cuda(dq), _cuda(x0), want=('x', 'err'), layout='ktc', in_layout='kct', final_state=True)
+            for out, lay in ((a, 'kct'), (b, 'kct'), (c, 'ktc')):
+                for key in ('x', 'err'):
+                    assert rel_err(uvs.engine.as_tkc(out[key], lay).cpu().numpy(), uvs.engine.as_tkc(ref[key], 'kct').cpu().numpy()) <= 1e-12, (T, K, key, lay)
+                for key in ('x_final', 'p_final'):
+                    assert rel_err(out[key].cpu().numpy(), ref[key].cpu().numpy()) <= 1e-12, (T, K, key)
+                assert int(out['status'].sum()) == 0 and np.all(out['k_done'].cpu().numpy() == K), (T, K)
+            assert rel_err(a['dqcmd'].cpu().numpy(), ref['dqcmd'].cpu().numpy()) <= 1e-9, (T, K)
+
+
 @pytest.mark.parametrize('T', [48, 35])
 @pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF', 'MCKF'])
 def test_estimator_only_replay_record_layout(uvs, method, T):
