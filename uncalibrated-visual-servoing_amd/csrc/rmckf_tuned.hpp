@@ -280,9 +280,17 @@ UVS_DEV void row_hook(Hook &hook) {
     }
 }
 
-template <int N, int METHOD, typename Hook>
+// Share: KF and IMCC-KF weigh every row of a filter alike (gain factor 1 / (a + 1) resp. c / (c a + 1) with ONE c), so their covariance
+// blocks stay identical for all rows: P_i <- P_i + I - beta g g^T with g = (P_i + I) h, and beta a function of h^T g alone.  A kernel may
+// keep one block per lane: the leading row runs the full update and leaves g and the gain factor in a RowShare, the other rows of the lane
+// only move their x (rmckf_row_follow: 20 instructions instead of 127).  Same operations on the same values: bit-identical results.
+struct NoShare {};
+template <int N>
+struct RowShare { double g[N]; double gamma; };
+
+template <int N, int METHOD, typename Hook, typename Share>
 UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
-                       double reg, double &kap, double &chk, FpiProbe &fpi, Hook &hook) {
+                       double reg, double &kap, double &chk, FpiProbe &fpi, Hook &hook, Share &share) {
     static_assert(std::is_same<Hook, NoHook>::value || N == 6, "hook points are placed for n = 6");
     double g[N];
     double pred = 0.0;
@@ -341,6 +349,12 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         gamma = fast_rcp(a + 1.0);
     }
     row_hook<4>(hook);
+    if constexpr (!std::is_same<Share, NoShare>::value) {
+        static_assert(METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF, "only estimators with one gain factor per filter share a block");
+#pragma unroll
+        for (int j = 0; j < N; ++j) share.g[j] = g[j];
+        share.gamma = gamma;
+    }
     const double step = gamma * nu;
     const double beta = gamma * (2.0 - gamma * (a + 1.0));
 #pragma unroll
@@ -362,11 +376,32 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 #endif
 }
 
+template <int N, int METHOD, typename Hook>
+UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
+                       double reg, double &kap, double &chk, FpiProbe &fpi, Hook &hook) {
+    NoShare none;
+    rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, reg, kap, chk, fpi, hook, none);
+}
+
 template <int N, int METHOD>
 UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&dq)[N], double zi, double neg_half_inv_s2, double c_shared,
                        double reg, double &kap, double &chk, FpiProbe &fpi) {
     NoHook none;
     rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, reg, kap, chk, fpi, none);
+}
+
+// A row whose covariance block is the leading row's (see RowShare): innovation and state update only (experiment.py:274, 291).
+template <int N>
+UVS_DEV void rmckf_row_follow(double (&x)[N], const RowShare<N> &share, const double (&dq)[N], double zi, double &chk) {
+    double pred = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
+    const double step = share.gamma * (zi - pred);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        x[j] = fma(share.g[j], step, x[j]);
+        chk = fma(x[j], 0.0, chk);
+    }
 }
 
 template <int N, int METHOD>
@@ -455,7 +490,7 @@ struct PlantLds {
 // the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
 // issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
-__global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
+__global__ __launch_bounds__(64, ((L >= 4 || ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2)) ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
@@ -466,10 +501,11 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;       // rows per lane, packed block size, trials per wavefront
     static_assert(PV >= 0 && PV <= R, "PV counts covariance blocks");
     constexpr int PL = R - PV;                                     // blocks resident in LDS
+    constexpr bool SHARED_P = (METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1;   // identical blocks: keep one (RowShare)
     using PC = PlantLds<M, N>;
     __shared__ double lds_x[XREG ? 1 : R * N][64];
     __shared__ double lds_acc[3 * R][64];
-    __shared__ double lds_p[PL > 0 ? PL * NP : 1][64];
+    __shared__ double lds_p[(PL > 0 && !((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1)) ? PL * NP : 1][64];
     __shared__ double lds_c[PC::kCount];
 
     const unsigned lane = threadIdx.x;
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                 for (int j = l; j < N; ++j) {
                     const double v = (l == j) ? 1.0 : 0.0;                     // P = I (experiment.py:73)
                     if (r < PV) p[r < PV ? r : 0][Sym<N>::at(l, j)] = v;
-                    else lds_p[(r - PV) * NP + Sym<N>::at(l, j)][lane] = v;
+                    else if constexpr (!SHARED_P) lds_p[(r - PV) * NP + Sym<N>::at(l, j)][lane] = v;
                 }
     }
     __syncthreads();                                               // lds_c is read by every lane
@@ -760,6 +796,7 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             flagged |= alive && (pair_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0);
         }
         double m_gamma[R], m_a[R], m_nu[R], m_z[R];              // MCKF: what the undo of a row needs (dead code for the other estimators)
+        RowShare<N> share;
         double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -769,9 +806,19 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
             double x[N], pb[NP];
 #pragma unroll
             for (int j = 0; j < N; ++j) x[j] = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
+            if constexpr (SHARED_P) {                                // one covariance block per lane (KF, IMCC-KF): p[0]
+                if (r == 0) {
+                    NoHook none;
+                    rmckf_row<N, METHOD>(x, p[0], dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi, none, share);
+                } else {
+                    rmckf_row_follow<N>(x, share, dq, zi, chk);
+                    kap[r] = 1.0;
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-            rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
+                for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
+                rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
+            }
             if constexpr (METHOD == UVS_METHOD_MCKF) { m_gamma[r] = fpi.row_gamma; m_a[r] = fpi.row_a; m_nu[r] = fpi.row_nu; m_z[r] = zi; }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -789,10 +836,12 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
                     pxr += L * N * A.x_out.sc;
                 }
             }
+            if constexpr (!SHARED_P) {
 #pragma unroll
-            for (int e = 0; e < NP; ++e) {
-                if (r < PV) p[r < PV ? r : 0][e] = pb[e];
-                else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
+                for (int e = 0; e < NP; ++e) {
+                    if (r < PV) p[r < PV ? r : 0][e] = pb[e];
+                    else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
+                }
             }
         }
         if constexpr (XOUT) px += UVS_SK(A.x_out.sk);
@@ -1021,7 +1070,8 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : 1)) void closed_loop_tuned_kernel
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) =
-                        (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
+                        SHARED_P ? p[0][Sym<N>::at(l, j)]
+                                 : (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }
 }
 
