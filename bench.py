@@ -455,6 +455,28 @@ def main():
         replay = None
         if world == 1 and args.config == 2 and not args.no_replay and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
             replay = replay_side_measurement(torch, engine, uvs_amd, fp, bufs['x'], bufs['err'], T, K, M, N)
+        others = None
+        if world == 1 and args.config == 2 and not args.no_side and not args.stats_only and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
+            # the reference's other three estimators on the headline workload: same inputs, same streams logged
+            others = {}
+            fp_head = fp
+            for meth in ('KF', 'IMCCKF', 'MCKF'):
+                fp = engine.make_params(M, N, meth, fp_head.kernel_bw, bool(fp_head.annealing), fp_head.dt, fp_head.dt * fp_head.k_max, fp_head.gain,
+                                        list(fp_head.desired)[:M], bool(fp_head.initial_guess), args.lanes)
+                ms = []
+                for i in range(2 + 5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    launch()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        ms.append(e0.elapsed_time(e1))
+                upd = int(k_done.sum().item())
+                avg = float(np.mean(ms))
+                others[meth] = {'avg_kernel_ms': avg, 'updates_per_s': upd / (avg * 1e-3), 'achieved': upd * b_alg / (avg * 1e-3) / 1e9, 'unit': 'GB/s',
+                                'frac': upd * b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches_timed': 5, 'failed_trials': int((status != 0).sum().item())}
+            fp = fp_head
         side = {}
         if world == 1 and args.config == 2 and not args.no_side and not args.stats_only and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
             for key in list(bufs):
@@ -476,7 +498,7 @@ def main():
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
             'cpu_baseline': cpu,
             'replay': replay,
-            'config3': side.get('config3'), 'config5': side.get('config5'),
+            'config3': side.get('config3'), 'config5': side.get('config5'), 'other_estimators': others,
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},
