@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Closed-loop sweep of BASELINE config 2 (65 536 trials x 299 updates, X + err + q logged) for each of the reference's estimators:
+average kernel time over a few launches.  Run on the GPU box; UVS_LIB_PATH selects an experiment build."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import uvs_amd
+from uvs_amd import engine, batch
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--methods', default='GMCKF,KF,IMCCKF,MCKF')
+ap.add_argument('--trials', type=int, default=65536)
+ap.add_argument('--reps', type=int, default=8)
+ap.add_argument('--lanes', type=int, default=0)
+args = ap.parse_args()
+T, dev = args.trials, torch.device('cuda')
+cfg = bench.config2()
+cfg['experiments']['epoch'] = T
+K = len(engine.loop_clock(0.05, 15))
+plan = batch.plan_trials(cfg, cells=[1.5])
+noise = batch.device_noise(cfg, plan, 0, T, K, dev)
+q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
+plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+for meth in args.methods.split(','):
+    fp = engine.make_params(8, 6, meth, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+    ms = []
+    for i in range(2 + args.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+        e1.record(); torch.cuda.synchronize()
+        if i >= 2:
+            ms.append(e0.elapsed_time(e1))
+    upd = int(out['k_done'].sum())
+    print(f'{meth:7s} lanes={args.lanes}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f})  {upd / np.mean(ms) / 1e6:.2f} G updates/s  {upd * 560 / np.mean(ms) / 1e9:.2f} TB/s  failed {int((out["status"] != 0).sum())}')

@@ -489,8 +489,12 @@ struct PlantLds {
 // With L = 4 the whole state fits the 256 VALU-addressable registers (P: 84, X: 24), LDS holds only the statistics and
 // the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
 // issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
+#ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
+#define UVS_SHARED_OCC 2
+#endif
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
-__global__ __launch_bounds__(64, ((L >= 4 || ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2)) ? 2 : 1)) void closed_loop_tuned_kernel(const ClosedArgs A) {
+__global__ __launch_bounds__(64, (L >= 4 ? 2 : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
+void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
