@@ -511,6 +511,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     __shared__ double lds_acc[3 * R][64];
     __shared__ double lds_p[(PL > 0 && !((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1)) ? PL * NP : 1][64];
     __shared__ double lds_c[PC::kCount];
+#ifdef UVS_LDS_PAD_KB                   // experiment builds: dead LDS that caps the wavefronts per CU (occupancy A/B of one and the same code)
+    __shared__ double lds_pad[UVS_LDS_PAD_KB * 128];
+    lds_pad[threadIdx.x] = 0.0;
+    asm volatile("" ::"v"(&lds_pad[threadIdx.x]) : "memory");
+#endif
 
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
