@@ -2,6 +2,7 @@
 // build: hipcc -O3 --offload-arch=gfx950 tools/ubench/ldsops.hip -o tools/ubench/ldsops
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef double double2v __attribute__((ext_vector_type(2)));
@@ -46,7 +47,7 @@ KERNEL(k_r128_spread, R12("ds_read_b128 %0, %9 offset:4096\n" FMA64))
 KERNEL(k_r128_burst, R12("ds_read_b128 %0, %9 offset:4096\n") FMA768)
 
 typedef void (*kern_t)(double *, unsigned long long *, double);
-int main() {
+int main(int argc, char **argv) {
     setvbuf(stdout, NULL, _IONBF, 0);
     struct { const char *name; kern_t fn; } tab[] = {
         {"no LDS", k_none}, {"12 ds_write_b64 spread", k_w64_spread}, {"12 ds_write_b64 burst", k_w64_burst},
@@ -54,7 +55,8 @@ int main() {
         {"12 ds_write_b128 spread", k_w128_spread}, {"12 ds_write_b128 burst", k_w128_burst},
         {"12 ds_read_b64 spread", k_r64_spread}, {"12 ds_read2st64_b64 spread", k_r2_spread}, {"12 ds_read2st64_b64 burst", k_r2_burst},
         {"12 ds_read_b128 spread", k_r128_spread}, {"12 ds_read_b128 burst", k_r128_burst}};
-    const int blocks = 1024;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 1024;             // 1024 = one wavefront per SIMD; 256 / 512: one / two wavefronts per CU
+    printf("%d wavefronts\n", blocks);
     double base = 0;
     for (auto &e : tab) {
         double *out; unsigned long long *cyc;
