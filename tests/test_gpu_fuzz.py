@@ -1,0 +1,62 @@
+"""Randomised cross-check of the closed-loop kernels against the C oracle (oracle/c): estimator, lane variant, horizon, gain, step,
+bandwidth, annealing and noise scale drawn at random (fixed seed); short horizons keep the closed loop's sensitivity out of the
+comparison, so the gates are tight."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def uvs():
+    import torch
+    assert torch.cuda.is_available()
+    import uvs_amd
+    uvs_amd.lib()
+    return uvs_amd
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def test_random_configurations_match_c_oracle(uvs):
+    import torch
+    from oracle import c_oracle
+    import bench
+    cfg = bench.config2()
+    desired = cfg['experiments']['desired_f']
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    rng = np.random.default_rng(2026)
+    worst = {}
+    for case in range(36):
+        method = ['GMCKF', 'KF', 'IMCCKF'][case % 3]                           # the estimators oracle/c restates
+        lanes = {'GMCKF': [0, 2, 4, 5, 1, -2], 'KF': [0, 2, 4, 5, -4], 'IMCCKF': [0, 2, 4, 5, -2]}[method]
+        lane = lanes[(case // 3) % len(lanes)]
+        T = int(rng.integers(1, 140))
+        K = int(rng.integers(1, 60))
+        dt = float(rng.choice([0.02, 0.05, 0.1]))
+        t_max = dt * (K + 1) + (dt / 2 if rng.random() < 0.5 else 5.0)          # k_max >= K; sometimes a much longer annealing horizon
+        gain = float(rng.uniform(0.05, 0.6))
+        bw = float(rng.choice([2.0, 10.0, 50.0]))
+        anneal = bool(rng.random() < 0.4)
+        scale = float(rng.choice([0.0, 0.5, 3.0]))
+        noise = scale * rng.standard_t(2.5, size=(T, K, 8))
+        q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
+        q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
+        ref = c_oracle.closed_loop_batch(q0, noise, desired, method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True)
+        fp = uvs.engine.make_params(8, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K)
+        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0)), device='cuda'),
+                                     want=('x', 'err', 'q'))
+        tag = (case, method, lane, T, K, dt, gain, bw, anneal, scale)
+        assert np.array_equal(out['status'].cpu().numpy(), ref['status']) and np.array_equal(out['k_done'].cpu().numpy(), ref['k_done']), tag
+        ok = ref['status'] == 0
+        if not ok.any():
+            continue
+        for key, rk, tol in (('err', 'err', 1e-8), ('q', 'q', 1e-8), ('x', 'X', 1e-8)):
+            a = out[key].cpu().numpy().transpose(2, 0, 1)[ok]
+            d = rel_err(a, ref[rk][ok])
+            worst[key] = max(worst.get(key, 0.0), d)
+            assert d <= tol, (key, d) + tag
+        assert rel_err(out['stats'].cpu().numpy()[ok], ref['stats'][ok]) <= 1e-8, tag
+    print('fuzz: worst relative deviations', {k: f'{v:.1e}' for k, v in worst.items()})
