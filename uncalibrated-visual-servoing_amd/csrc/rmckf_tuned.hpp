@@ -534,6 +534,8 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
     double *pq = A.q_out.p ? A.q_out.at(trial, 0, grp * JG) : nullptr;
     double *pd = A.dq_out.p ? A.dq_out.at(trial, 0, grp * JG) : nullptr;
+    // Component addresses are formed from the step cursor with the whole index expression (cursor + (row, column) * comp_stride), not by
+    // walking a second pointer: one live 64-bit value per stream instead of two -- which is what kept the MCKF instantiation out of scratch.
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
 
@@ -617,9 +619,8 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
     for (int r = 0; r < R; ++r) nz_next[r] = 0.0;
     if (on_noise && K > 0) {
-        const double *pr = pn;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { nz_next[r] = *pr; pr += L * A.noise.sc; }
+        for (int r = 0; r < R; ++r) nz_next[r] = pn[r * L * A.noise.sc];
         pn += A.noise.sk;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
@@ -644,9 +645,8 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
         for (int r = 0; r < R; ++r) nz[r] = nz_next[r];
         if (on_noise && k + 1 < K) {
-            const double *pr = pn;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { nz_next[r] = *pr; pr += L * A.noise.sc; }
+            for (int r = 0; r < R; ++r) nz_next[r] = pn[r * L * A.noise.sc];
             pn += A.noise.sk;
         }
         // ---- plant: noise-free features of this lane's rows
@@ -806,7 +806,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
         double m_gamma[R], m_a[R], m_nu[R], m_z[R];              // MCKF: what the undo of a row needs (dead code for the other estimators)
         RowShare<N> share;
-        double *pxr = px;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double fi = z[r] + nz[r];                      // noisy feature (experiment.py:134-135)
@@ -839,10 +838,8 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 if (k == K - 1)
 #endif
                 {
-                    double *pc = pxr;
 #pragma unroll
-                    for (int j = 0; j < N; ++j) { *pc = x[j]; pc += A.x_out.sc; }
-                    pxr += L * N * A.x_out.sc;
+                    for (int j = 0; j < N; ++j) px[(r * L * N + j) * A.x_out.sc] = x[j];
                 }
             }
             if constexpr (!SHARED_P) {
@@ -938,9 +935,8 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                             }
                         }
                         if constexpr (XOUT) {
-                            double *pc = pxs + (long long)r * L * N * A.x_out.sc;
 #pragma unroll
-                            for (int j = 0; j < N; ++j) { *pc = x[j]; pc += A.x_out.sc; }
+                            for (int j = 0; j < N; ++j) pxs[((long long)r * L * N + j) * A.x_out.sc] = x[j];
                         }
                     }
                 }
@@ -989,15 +985,13 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 
         // ---- logs and statistics
         if (on_err) {
-            double *pc = pe;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { *pc = err[r]; pc += L * A.err_out.sc; }
+            for (int r = 0; r < R; ++r) pe[r * L * A.err_out.sc] = err[r];
             pe += UVS_SK(A.err_out.sk);
         }
         if (on_f) {
-            double *pc = pf;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { *pc = f_prev[r]; pc += L * A.f_out.sc; }
+            for (int r = 0; r < R; ++r) pf[r * L * A.f_out.sc] = f_prev[r];
             pf += A.f_out.sk;
         }
         double dq_own[JG];                                       // the command for this lane's joints
@@ -1008,15 +1002,13 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             else dq_own[u] = (grp == 0) ? in_reg(dq[u]) : (grp == 1 ? in_reg(dq[JG + u]) : in_reg(dq[2 * JG + u]));
         }
         if (on_q) {
-            double *pc = pq;
 #pragma unroll
-            for (int u = 0; u < JG; ++u) { *pc = q[u]; pc += A.q_out.sc; }
+            for (int u = 0; u < JG; ++u) pq[u * A.q_out.sc] = q[u];
             pq += UVS_SK(A.q_out.sk);
         }
         if (on_dq) {
-            double *pc = pd;
 #pragma unroll
-            for (int u = 0; u < JG; ++u) { *pc = dq_own[u]; pc += A.dq_out.sc; }
+            for (int u = 0; u < JG; ++u) pd[u * A.dq_out.sc] = dq_own[u];
             pd += A.dq_out.sk;
         }
 #pragma unroll
