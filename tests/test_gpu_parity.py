@@ -147,6 +147,35 @@ def test_replay_control_wavefronts(uvs, method):
             assert int(a['k_done'][149]) == 40 and int(a['status'][149]) == 1 and int(a['status'].sum()) == 1
 
 
+def test_replay_default_kernels_full_horizon(uvs):
+    """4 096 trials x 299 steps through the three default replay mappings (row-group wavefronts, + control wavefronts, record path) and the
+    two-lane kernel: estimator streams equal to 1e-12, commanded dq to 1e-9 (normal equations vs Householder), no trial fails."""
+    import torch
+    g = load_golden('closed_gmckf_a1p5')
+    T, K = 4096, 299
+    gen = torch.Generator(device='cuda').manual_seed(21)
+    rnd = lambda *shape: torch.randn(shape, device='cuda', dtype=torch.float64, generator=gen)      # noqa: E731
+    J = rnd(8, 6, T) * 50
+    dq = rnd(K, 6, T) * 0.2
+    f = torch.empty((K + 1, 8, T), device='cuda', dtype=torch.float64)
+    f[0] = 128 + 20 * rnd(8, T)
+    for k in range(K):
+        f[k + 1] = f[k] + torch.einsum('mnt,nt->mt', J, dq[k]) * 0.05 + rnd(8, T)
+    x0 = (J + 5 * rnd(8, 6, T)).permute(2, 0, 1).reshape(T, 48).contiguous()
+    ref = uvs.engine.replay(_fp(uvs, g, 2, steps=K), f, dq, x0, want=('x', 'err', 'dqcmd'), final_state=True)
+    a = uvs.engine.replay(_fp(uvs, g, 0, steps=K), f, dq, x0, want=('x', 'err', 'dqcmd'), final_state=True)
+    b = uvs.engine.replay(_fp(uvs, g, 0, steps=K), f, dq, x0, want=('x', 'err'), final_state=True)
+    c = uvs.engine.replay(_fp(uvs, g, 0, steps=K), f, dq, x0, want=('x', 'err'), layout='ktc', in_layout='kct', final_state=True)
+    for out, lay in ((a, 'kct'), (b, 'kct'), (c, 'ktc')):
+        for key in ('x', 'err'):
+            d = (uvs.engine.as_tkc(out[key], lay) - uvs.engine.as_tkc(ref[key], 'kct')).abs().max() / uvs.engine.as_tkc(ref[key], 'kct').abs().max()
+            assert float(d) <= 1e-12, (key, lay, float(d))
+        assert float((out['p_final'] - ref['p_final']).abs().max() / ref['p_final'].abs().max()) <= 1e-12
+        assert int(out['status'].sum()) == 0 and bool((out['k_done'] == K).all())
+    d = (a['dqcmd'] - ref['dqcmd']).abs().max() / ref['dqcmd'].abs().max()
+    assert float(d) <= 1e-9, float(d)
+
+
 def test_replay_default_kernels_edge_sizes(uvs):
     """The library-default replay mappings (row-group wavefronts, + control wavefronts with the commanded dq, record path) at the edges:
     one trial, one short of / exactly / one past a 64-trial workgroup, horizons of 1, 2 and 3 steps -- against the two-lane kernel."""
