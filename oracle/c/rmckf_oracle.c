@@ -6,6 +6,9 @@
  *   experiment.py:125-343  loop (measurement, estimator, control law, actuation)
  *   experiment.py:166-167  predict            :170-188 measurement / regressor
  *   experiment.py:191-193  KF                  :251-265 IMCCKF            :266-294 GMCKF (the paper's RMCKF)
+ *   experiment.py:194-250  MCKF: fixed-point iteration per step (Cholesky factor of every predicted block, weights Cx / Cy, stop test
+ *                          over all rows, a zero Cy or the epoch cap skips the correction; a weight whose reciprocal overflows
+ *                          turns the dense products of the reference into NaN and the trial FAILs)
  *   experiment.py:296-297  Joseph covariance update (evaluated as written: A P A^T + k k^T per block)
  *   experiment.py:300-316  control law with numpy.linalg.pinv semantics (SVD, singular values <= 1e-15 * max dropped;
  *                          a non-finite Jacobian makes pinv raise -> FAIL)
@@ -25,6 +28,8 @@ typedef struct {
     int32_t m, n, method, annealing, k_max, steps, initial_guess, pad;
     double kernel_bw, anneal_span, gain, dt, reg;
     double desired[MAXM];
+    double fpi_threshold;
+    int32_t fpi_epoch_max, pad2;
 } oracle_params;
 
 typedef struct {
@@ -171,10 +176,102 @@ static void initial_guess(const oracle_plant *pl, const double *q, int m, int n,
     }
 }
 
+/* Fixed-point MCKF correction of one step (experiment.py:194-250) on the predicted blocks P (already P + Q).  Z: measurement, h: regressor.
+ * Updates X and P in place; returns the reference's `epoch` counter (passes completed; 0 when the first pass met a zero weight). */
+static int mckf_step(int m, int n, double *X, double P[][MAXN * MAXN], const double *Z, const double *h, double bw, double thr, int cap) {
+    static const double kInf = 1.0 / 0.0;
+    double L[MAXM][MAXN * MAXN], nu0[MAXM], Xc[MAXM * MAXN], kk[MAXM * MAXN];
+    for (int i = 0; i < m; ++i) {                                /* Bp = cholesky(P), block by block (:203) */
+        for (int j = 0; j < n; ++j)
+            for (int r = 0; r < n; ++r) L[i][r * n + j] = 0;
+        for (int j = 0; j < n; ++j) {
+            double d = P[i][j * n + j];
+            for (int c = 0; c < j; ++c) d -= L[i][j * n + c] * L[i][j * n + c];
+            const double ljj = sqrt(d);
+            L[i][j * n + j] = ljj;
+            for (int r = j + 1; r < n; ++r) {
+                double v = P[i][r * n + j];
+                for (int c = 0; c < j; ++c) v -= L[i][r * n + c] * L[i][j * n + c];
+                L[i][r * n + j] = v / ljj;
+            }
+        }
+        nu0[i] = Z[i];
+        for (int j = 0; j < n; ++j) nu0[i] -= X[i * n + j] * h[j];    /* Z - H X: the gain is applied to the prior innovation (:242) */
+    }
+    memcpy(Xc, X, sizeof(double) * m * n);
+    for (int i = 0; i < m * n; ++i) kk[i] = 0;
+    double diff = kInf;
+    int it = 0, skip = 0;
+    while (diff > thr && it < cap) {                             /* :213 */
+        double cx[MAXM][MAXN], cy[MAXM];
+        int zero = 0, poison = 0;
+        for (int i = 0; i < m; ++i) {
+            double ex[MAXN], ez = Z[i];
+            for (int r = 0; r < n; ++r) {                        /* L ex = x - xc (rows of D - W Xc, :215) */
+                double v = X[i * n + r] - Xc[i * n + r];
+                for (int c = 0; c < r; ++c) v -= L[i][r * n + c] * ex[c];
+                ex[r] = v / L[i][r * n + r];
+                cx[i][r] = gaussian_kernel(ex[r], bw);
+                if (isinf(1.0 / cx[i][r])) poison = 1;          /* inv(Cx): inf entries (or, for an exact 0, an uncaught LinAlgError) */
+            }
+            for (int j = 0; j < n; ++j) ez -= Xc[i * n + j] * h[j];
+            cy[i] = gaussian_kernel(ez, bw);
+            if (cy[i] == 0.0) zero = 1;
+            else if (isinf(1.0 / cy[i])) poison = 1;
+        }
+        if (zero) { skip = 1; break; }                           /* inv(Cy) raises: skip the correction (:225-236) */
+        double num = 0, den = 0;
+        for (int i = 0; i < m; ++i) {
+            double t[MAXN], g[MAXN], a = 0;
+            for (int j = 0; j < n; ++j) {                        /* t = Cx^-1 L^T h */
+                double v = 0;
+                for (int r = j; r < n; ++r) v += L[i][r * n + j] * h[r];
+                t[j] = v / cx[i][j];
+            }
+            for (int r = 0; r < n; ++r) {                        /* g = L t = P_hat h */
+                double v = 0;
+                for (int c = 0; c <= r; ++c) v += L[i][r * n + c] * t[c];
+                g[r] = v;
+                a += h[r] * v;
+            }
+            const double s = a + 1.0 / cy[i];
+            for (int l = 0; l < n; ++l) {
+                /* 0 * inf of the reference's dense Br Cy^-1 Br^T / Bp Cx^-1 Bp^T poisons the whole gain (:223, :232) */
+                kk[i * n + l] = poison ? kInf - kInf : g[l] / s;
+                const double xn = X[i * n + l] + kk[i * n + l] * nu0[i];
+                num += (xn - Xc[i * n + l]) * (xn - Xc[i * n + l]);
+                den += Xc[i * n + l] * Xc[i * n + l];
+                Xc[i * n + l] = xn;
+            }
+        }
+        diff = sqrt(num) / sqrt(den);                            /* :244 */
+        ++it;
+        if (it == cap) skip = 1;                                 /* :246-248 */
+    }
+    if (!skip) {
+        for (int i = 0; i < m; ++i) {                            /* X = X_corrected; Joseph with the final gain (:250, :297) */
+            double AP[MAXN * MAXN], hp[MAXN];
+            for (int j = 0; j < n; ++j) {
+                X[i * n + j] = Xc[i * n + j];
+                hp[j] = 0;
+                for (int l = 0; l < n; ++l) hp[j] += h[l] * P[i][l * n + j];
+            }
+            for (int l = 0; l < n; ++l)
+                for (int j = 0; j < n; ++j) AP[l * n + j] = P[i][l * n + j] - kk[i * n + l] * hp[j];
+            for (int l = 0; l < n; ++l) {
+                double aph = 0;
+                for (int j = 0; j < n; ++j) aph += AP[l * n + j] * h[j];
+                for (int j = 0; j < n; ++j) P[i][l * n + j] = AP[l * n + j] - aph * kk[i * n + j] + kk[i * n + l] * kk[i * n + j];
+            }
+        }
+    }
+    return it;
+}
+
 /* One trial.  noise: [K][m] or NULL; x0: [m*n] when !initial_guess.  Outputs (any may be NULL): err [K][m], q_log [K][n],
- * x_log [K][m*n], stats [3].  Returns status (0 success, 1 fail); *k_done receives the number of logged rows. */
+ * x_log [K][m*n], stats [3], fpi_log [K] (MCKF passes per step).  Returns status (0 success, 1 fail); *k_done receives the number of logged rows. */
 int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, const double *q_start, const double *noise, const double *x0,
-                           double *err_log, double *q_log, double *x_log, double *stats, int32_t *k_done) {
+                           double *err_log, double *q_log, double *x_log, double *stats, int32_t *k_done, int32_t *fpi_log) {
     const int m = fp->m, n = fp->n, K = fp->steps;
     double X[MAXM * MAXN], P[MAXM][MAXN * MAXN], q[MAXN], dq[MAXN], f[MAXM], f_old[MAXM], T[MAXN][16];
     double ise[MAXM] = {0}, iae[MAXM] = {0}, itae[MAXM] = {0};
@@ -210,7 +307,17 @@ int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, cons
             for (int i = 0; i < m; ++i) ss += nu[i] * nu[i];
             cs = gaussian_kernel(sqrt(ss), sigma);
         }
-        for (int i = 0; i < m; ++i) {
+        if (fp->method == 3) {                                   /* MCKF */
+            double Z[MAXM];
+            for (int i = 0; i < m; ++i) {
+                Z[i] = f[i] - f_old[i];
+                kappa[i] = 1;
+                for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
+            }
+            const int it = mckf_step(m, n, X, P, Z, dq, sigma, fp->fpi_threshold, fp->fpi_epoch_max);
+            if (fpi_log) fpi_log[k] = it;
+        }
+        for (int i = 0; i < m && fp->method != 3; ++i) {
             double g[MAXN], kk[MAXN], a = 0;
             for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
             for (int l = 0; l < n; ++l) {
@@ -262,9 +369,10 @@ int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, cons
 
 /* Batch driver: trials t = 0..T-1 with per-trial q_start [T][n], noise [T][K][m]; outputs [T][K][...] (may be NULL). */
 void uvs_oracle_closed_loop_batch(const oracle_params *fp, const oracle_plant *pl, int64_t T, const double *q_start, const double *noise,
-                                  double *err_log, double *q_log, double *x_log, double *stats, int32_t *status, int32_t *k_done) {
+                                  double *err_log, double *q_log, double *x_log, double *stats, int32_t *status, int32_t *k_done, int32_t *fpi_log) {
     const size_t K = fp->steps, m = fp->m, n = fp->n;
     for (int64_t t = 0; t < T; ++t)
         status[t] = uvs_oracle_closed_loop(fp, pl, q_start + t * n, noise ? noise + t * K * m : 0, 0, err_log ? err_log + t * K * m : 0,
-                                           q_log ? q_log + t * K * n : 0, x_log ? x_log + t * K * m * n : 0, stats ? stats + 3 * t : 0, k_done + t);
+                                           q_log ? q_log + t * K * n : 0, x_log ? x_log + t * K * m * n : 0, stats ? stats + 3 * t : 0, k_done + t,
+                                           fpi_log ? fpi_log + t * K : 0);
 }

@@ -7,13 +7,14 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, 'c', 'liboracle_rmckf.so')
-METHOD = {'KF': 2, 'IMCCKF': 4, 'GMCKF': 5}
+METHOD = {'KF': 2, 'MCKF': 3, 'IMCCKF': 4, 'GMCKF': 5}
 
 
 class Params(C.Structure):
     _fields_ = [('m', C.c_int32), ('n', C.c_int32), ('method', C.c_int32), ('annealing', C.c_int32), ('k_max', C.c_int32),
                 ('steps', C.c_int32), ('initial_guess', C.c_int32), ('pad', C.c_int32), ('kernel_bw', C.c_double),
-                ('anneal_span', C.c_double), ('gain', C.c_double), ('dt', C.c_double), ('reg', C.c_double), ('desired', C.c_double * 32)]
+                ('anneal_span', C.c_double), ('gain', C.c_double), ('dt', C.c_double), ('reg', C.c_double), ('desired', C.c_double * 32),
+                ('fpi_threshold', C.c_double), ('fpi_epoch_max', C.c_int32), ('pad2', C.c_int32)]
 
 
 class Plant(C.Structure):
@@ -27,7 +28,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(PATH):
+        src = os.path.join(HERE, 'c', 'rmckf_oracle.c')
+        if not os.path.exists(PATH) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(PATH)):
             subprocess.run(['make', '-C', os.path.join(HERE, 'c')], check=True)
         _lib = C.CDLL(PATH)
     return _lib
@@ -47,8 +49,8 @@ def ur10_plant():
 
 
 def closed_loop_batch(q_start, noise, desired, method='GMCKF', kernel_bw=10.0, annealing=False, dt=0.05, t_max=15.0, gain=0.2,
-                      steps=None, want_x=False, plant=None):
-    """q_start (T, n), noise (T, K, m) -> dict(err (T,K,m), q (T,K,n), X (T,K,mn)?, stats (T,3), status, k_done)."""
+                      steps=None, want_x=False, plant=None, fpi_threshold=0.1, fpi_epoch_max=1000):
+    """q_start (T, n), noise (T, K, m) -> dict(err (T,K,m), q (T,K,n), X (T,K,mn)?, stats (T,3), status, k_done, fpi (T,K) MCKF passes per step)."""
     q_start, noise = np.ascontiguousarray(q_start, float), np.ascontiguousarray(noise, float)
     T, K, m = noise.shape
     n = q_start.shape[1]
@@ -56,14 +58,16 @@ def closed_loop_batch(q_start, noise, desired, method='GMCKF', kernel_bw=10.0, a
     fp.m, fp.n, fp.method, fp.annealing, fp.k_max = m, n, METHOD[method], int(annealing), int(t_max / dt)
     fp.steps, fp.initial_guess = K if steps is None else steps, 1
     fp.kernel_bw, fp.anneal_span, fp.gain, fp.dt, fp.reg = kernel_bw, 100.0, gain, dt, 0.001 ** 2
+    fp.fpi_threshold, fp.fpi_epoch_max = fpi_threshold, fpi_epoch_max
     for i, v in enumerate(desired):
         fp.desired[i] = v
     pl = ur10_plant() if plant is None else plant
     err, q = np.zeros((T, K, m)), np.zeros((T, K, n))
     X = np.zeros((T, K, m * n)) if want_x else None
     stats, status, k_done = np.zeros((T, 3)), np.zeros(T, np.int32), np.zeros(T, np.int32)
+    fpi = np.zeros((T, fp.steps), np.int32)
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)     # noqa: E731
     fn = lib().uvs_oracle_closed_loop_batch
-    fn.restype, fn.argtypes = None, [C.POINTER(Params), C.POINTER(Plant), C.c_int64] + [C.c_void_p] * 8
-    fn(C.byref(fp), C.byref(pl), T, ptr(q_start), ptr(noise), ptr(err), ptr(q), ptr(X), ptr(stats), ptr(status), ptr(k_done))
-    return dict(err=err, q=q, X=X, stats=stats, status=status, k_done=k_done)
+    fn.restype, fn.argtypes = None, [C.POINTER(Params), C.POINTER(Plant), C.c_int64] + [C.c_void_p] * 9
+    fn(C.byref(fp), C.byref(pl), T, ptr(q_start), ptr(noise), ptr(err), ptr(q), ptr(X), ptr(stats), ptr(status), ptr(k_done), ptr(fpi))
+    return dict(err=err, q=q, X=X, stats=stats, status=status, k_done=k_done, fpi=fpi)

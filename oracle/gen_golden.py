@@ -115,7 +115,7 @@ def run_reference(method, noise_type, noise_params, seed, q_start=Q_START, hold=
     def local(frame, event, arg):
         if event == 'line' and frame.f_lineno == 302:
             L = frame.f_locals
-            rec.append({k: np.array(L[k], copy=True) for k in ('X', 'P', 'dq', 'e', 'kernel_bw') if k in L})
+            rec.append({k: np.array(L[k], copy=True) for k in ('X', 'P', 'dq', 'e', 'kernel_bw', 'epoch', 'skip_correction') if k in L})
         return local
 
     npf = NoiseProfiler(num_features=8, noise_type=noise_type, seed=seed, noise_hold=hold, noise_hold_cnt=hold_cnt,

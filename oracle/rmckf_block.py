@@ -80,9 +80,16 @@ class BlockFilter:
             if np.any(cy == 0.0):                                   # inv(Cy) raises LinAlgError (:231-236)
                 skip = True
                 break
-            P_hat = Lc @ (np.transpose(Lc, (0, 2, 1)) / cx[:, :, None])
-            g = P_hat @ h
-            kk = g / ((g @ h) + 1.0 / cy)[:, None]
+            with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
+                P_hat = Lc @ (np.transpose(Lc, (0, 2, 1)) / cx[:, :, None])
+                g = P_hat @ h
+                kk = g / ((g @ h) + 1.0 / cy)[:, None]
+                # A weight that is subnormal but not 0 (its reciprocal overflows): inv() returns inf without raising, and the DENSE products
+                # of the reference, Br @ inv(Cy) @ Br.T (:232) resp. Bp @ inv(Cx) @ Bp.T (:223), turn 0 * inf into NaN -- the whole gain, the
+                # state and with it the trial (pinv raises in the control law, :312-316).  A Cx of exactly 0 makes inv(Cx) raise outside any
+                # try (:223, the reference's sweep aborts); it is folded into the same FAIL here (policies).
+                if np.any(np.isinf(1.0 / cy)) or np.any(np.isinf(1.0 / cx)):
+                    kk = np.full((m, n), np.nan)
             Xc_old = Xc
             Xc = X + kk * nu0[:, None]
             diff = np.linalg.norm(Xc - Xc_old) / np.linalg.norm(Xc_old)
@@ -122,7 +129,7 @@ def run_replay(f_seq, dq_seq, x0, desired_f, gain, method=GMCKF, kernel_bw=10.0,
 
 
 def run_closed_loop(plant, q_start, desired_f, noise_seq, t_s, t_max, gain, x0, method=GMCKF,
-                    kernel_bw=10.0, annealing=False, initial_guess=True):
+                    kernel_bw=10.0, annealing=False, initial_guess=True, fpi_threshold=0.1, fpi_epoch_max=1000):
     """Closed loop on a functional plant: ``plant(q) -> f`` (noise-free features at joints q).
     ``noise_seq`` (K, m) or None.  ``initial_guess`` selects what the first ``f_old`` is: the noise-free features seen while
     forming the analytic X0 (experiment.py:90) or zeros when X0 is supplied (experiment.py:56).
@@ -130,12 +137,12 @@ def run_closed_loop(plant, q_start, desired_f, noise_seq, t_s, t_max, gain, x0, 
     desired_f = np.asarray(desired_f, float)
     m, n = len(desired_f), len(q_start)
     k_max = int(t_max / t_s)
-    filt = BlockFilter(m, n, x0, method, kernel_bw, annealing, k_max)
+    filt = BlockFilter(m, n, x0, method, kernel_bw, annealing, k_max, fpi_threshold, fpi_epoch_max)
     q = np.array(q_start, float)
     f = plant(q) if initial_guess else np.zeros(m)
     dq = np.zeros(n)
     t, k = t_s, 0                                                   # start() steps the clock once
-    ts, errs, qs, Xs = [], [], [], []
+    ts, errs, qs, Xs, its = [], [], [], [], []
     status = 0
     while t < t_max:
         f_old = f
@@ -146,9 +153,9 @@ def run_closed_loop(plant, q_start, desired_f, noise_seq, t_s, t_max, gain, x0, 
             status = 1
             break
         dq = control_law(filt.X, err, kappa, gain)
-        ts.append(t); errs.append(err); qs.append(q.copy()); Xs.append(filt.X.ravel().copy())
+        ts.append(t); errs.append(err); qs.append(q.copy()); Xs.append(filt.X.ravel().copy()); its.append(filt.fpi_iterations)
         k += 1
         q = q + dq * t_s
         t += t_s
     return dict(t=np.array(ts), err=np.array(errs), q=np.array(qs), X=np.array(Xs), status=status, k_done=k,
-                P_final=filt.P.copy())
+                P_final=filt.P.copy(), fpi_iterations=np.array(its))

@@ -58,6 +58,7 @@ class DenseFilter:
         self.Br = np.linalg.cholesky(self.R)
         self.Br_inv = np.linalg.inv(self.Br)
         self.first = True
+        self.fpi_iterations, self.fpi_skipped = 0, False
         self.kappa = np.ones(m)
         self.sigma = -1.0
 
@@ -103,6 +104,7 @@ class DenseFilter:
                 it += 1
                 if it == self.fpi_epoch_max:
                     skip = True
+            self.fpi_iterations, self.fpi_skipped = it, skip
             if not skip:
                 X = Xc
         elif self.method == IMCCKF:                                        # :251-265
@@ -160,7 +162,7 @@ def run_closed_loop(robot, q_start, desired_f, noise_next, t_s, t_max, gain, met
         raise ValueError('x0 required when initial_guess is False (reference draws it unseeded, experiment.py:117)')
     filt = DenseFilter(m, n, method, kernel_bw, annealing, k_max, fpi_threshold, fpi_epoch_max, x0)
     dq = np.zeros((n, 1))
-    logs = {key: [] for key in ('t', 'err', 'q', 'f', 'noise', 'cam', 'X', 'Pblk', 'dq', 'sigma', 'kappa')}
+    logs = {key: [] for key in ('t', 'err', 'q', 'f', 'noise', 'cam', 'X', 'Pblk', 'dq', 'sigma', 'kappa', 'fpi_iterations', 'fpi_skipped')}
     status, k = SUCCESS, 0
     while (t := robot.sim.getSimulationTime()) < t_max:
         f_old = f.copy()
@@ -170,6 +172,8 @@ def run_closed_loop(robot, q_start, desired_f, noise_next, t_s, t_max, gain, met
             f = f + noise
         kappa = filt.step(f - f_old, dq, k)
         err = f - desired_f
+        if capture and method == MCKF:                                     # recorded for the FAILing step too, like the tracer at experiment.py:302
+            logs['fpi_iterations'].append(filt.fpi_iterations); logs['fpi_skipped'].append(filt.fpi_skipped)
         try:
             dq = control_law(filt.X, m, n, err, kappa, gain)
         except np.linalg.LinAlgError:

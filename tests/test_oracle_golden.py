@@ -168,3 +168,78 @@ def test_block_replay_matches_reference_on_rank_deficient_jacobians(name):
     h = RANKDEF_HORIZON.get(name, len(g['t']))
     assert rel_err(out['X'][g['X_steps']][:h], g['X'][:h]) <= 1e-11
     assert rel_err(out['dq_cmd'][:h - 1], g['dq_prev'][1:h]) <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------------- MCKF fixed-point iteration (fpi_*)
+FPI = golden_names('fpi_')
+FPI_HORIZON = {}            # none of these runs amplifies rounding on this plant (block vs dense over the whole trial: <= 1e-11)
+
+
+def test_fpi_fixture_inventory():
+    """oracle/gen_golden_fpi.py: runs of the unmodified reference that take the multi-pass, epoch-cap, Cy = 0 and subnormal-Cy paths."""
+    assert FPI == ['fpi_default_a1p0_seed0', 'fpi_default_a1p0_seed38', 'fpi_mckf_a1p0_bw1_fail', 'fpi_mckf_a1p0_thr1em3', 'fpi_mckf_a1p2_cap3',
+                   'fpi_mckf_a1p2_cap4', 'fpi_mckf_a1p2_thr1em6_fail', 'fpi_mckf_a1p5_anneal_thr1em4', 'fpi_mckf_a1p5_thr1em6']
+    for name in FPI:
+        g = load_golden(name)
+        k, ep, sk = len(g['t']), g['fpi_epochs'], g['fpi_skip']
+        failed = int(g['status']) == 1
+        assert len(ep) == len(sk) == k + failed and g['noise_full'].shape == (299, 8) and np.array_equal(g['noise_full'][:k], g['noise'])
+        assert failed == (name.endswith('_fail') or 'default' in name) and (k == 299) != failed
+        if 'thr' in name or 'cap' in name:
+            assert int((ep >= 2).sum()) >= 10, name                  # the second and later passes really run
+        if 'cap' in name:
+            cap = g['meta']['params']['fpi_epoch_max']
+            assert ep.max() == cap and np.array_equal(sk[ep == cap], np.ones(int((ep == cap).sum()), bool)) and 10 <= int(sk.sum()) < k - 10
+        if 'a1p0' in name:
+            assert int((ep == 0).sum()) >= 2 and np.all(sk[ep == 0])   # a zero weight Cy: inv raises before the first pass completes
+        if failed:
+            assert not sk[-1] and ep[-1] == 1                          # subnormal Cy: one pass, NaN state, not a skipped correction
+
+
+@pytest.mark.parametrize('name', FPI)
+def test_dense_restatement_reproduces_reference_fpi(name):
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    it = iter(g['noise_full'])
+    out = rmckf_dense.run_closed_loop(
+        plant_ref.PinholeUR10(meta['dt']), g['q_start'], g['desired'], lambda: next(it), meta['dt'], meta['t_max'],
+        meta['gain'], method='MCKF', initial_guess=True, kernel_bw=p['kernel_bw'], annealing=p['annealing'],
+        fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'], capture=True)
+    k = len(g['t'])
+    assert out['status'] == int(g['status']) and out['k_done'] == k
+    assert np.array_equal(out['fpi_iterations'], g['fpi_epochs']) and np.array_equal(out['fpi_skipped'], g['fpi_skip'])
+    for key, ref in (('err', g['err']), ('q', g['q']), ('f', g['f'])):
+        assert rel_err(out[key], ref) <= 1e-9, key
+    assert rel_err(out['X'][g['X_steps']], g['X']) <= 1e-9
+
+
+@pytest.mark.parametrize('name', FPI)
+def test_block_replay_matches_reference_fpi(name):
+    """The reference's recorded streams through the per-row fixed-point iteration: X per step, iteration counts, skipped corrections."""
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    k = len(g['t'])
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    out = rmckf_block.run_replay(f_seq, g['dq_prev'], g['X'][0], g['desired'], meta['gain'], method='MCKF', kernel_bw=p['kernel_bw'],
+                                 annealing=p['annealing'], k_max=300, fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'])
+    assert np.array_equal(out['fpi_iterations'], g['fpi_epochs'][:k])
+    assert rel_err(out['X'][g['X_steps']], g['X']) <= 1e-10
+    assert rel_err(out['dq_cmd'][:-1], g['dq_prev'][1:]) <= 1e-8
+    if int(g['P_steps'][-1]) == k - 1:
+        assert rel_err(out['P_final'], g['P_blocks'][-1]) <= 1e-10
+
+
+@pytest.mark.parametrize('name', FPI)
+def test_block_closed_loop_matches_reference_fpi(name):
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    discs = plant_ref.place_discs()
+    out = rmckf_block.run_closed_loop(lambda q: plant_ref.project(plant_ref.fkine_all(q)[5], discs), g['q_start'], g['desired'],
+                                      g['noise_full'], meta['dt'], meta['t_max'], meta['gain'], g['X'][0], method='MCKF',
+                                      kernel_bw=p['kernel_bw'], annealing=p['annealing'], fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'])
+    k = len(g['t'])
+    h = min(k, FPI_HORIZON.get(name, k))
+    assert rel_err(out['err'][:h], g['err'][:h]) <= 1e-8 and rel_err(out['q'][:h], g['q'][:h]) <= 1e-8
+    assert np.array_equal(out['fpi_iterations'][:h], g['fpi_epochs'][:h])
+    if name not in FPI_HORIZON:
+        assert out['status'] == int(g['status']) and out['k_done'] == k
