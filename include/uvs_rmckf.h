@@ -62,9 +62,9 @@ typedef struct uvs_filter_params {
     int32_t k_max;              /* int(t_max/t_s) (:120)                                            */
     int32_t steps;              /* loop iterations K: number of t = t_s, 2 t_s, ... < t_max (:125)  */
     int32_t initial_guess;      /* 1: analytic interaction-matrix X0 (:86-114); 0: X0 from view     */
-    int32_t lanes_per_filter;   /* 0 = library default (tuned kernels: 2 lanes at (8,6) and (6,6), 8 at (32,7));  */
-                                /* L > 0: L lanes cooperate on a filter (tuned kernel where one exists; 5 at     */
-                                /* (8,6) = role-split variant: 4 estimator lanes + 1 control lane per trial);    */
+    int32_t lanes_per_filter;   /* 0 = library default (tuned kernels: 2 lanes at (8,6) and (6,6); 8 at (32,7) on */
+                                /* the linear plant with x0 supplied, else the generic template with 16);        */
+                                /* L > 0: L lanes cooperate on a filter (tuned kernel where one exists);         */
                                 /* L < 0: generic template with |L| lanes (in-library cross-check of tuned code) */
     double kernel_bw;           /* sigma_0 (:37)                                                    */
     double anneal_span;         /* 100 (:271)                                                       */

@@ -29,10 +29,10 @@ def test_random_configurations_match_c_oracle(uvs):
     plant = uvs.SyntheticPlant.ur10(desired).to_struct()
     rng = np.random.default_rng(2026)
     worst = {}
-    for case in range(36):
-        method = ['GMCKF', 'KF', 'IMCCKF'][case % 3]                           # the estimators oracle/c restates
-        lanes = {'GMCKF': [0, 2, 4, 5, 1, -2], 'KF': [0, 2, 4, 5, -4], 'IMCCKF': [0, 2, 4, 5, -2]}[method]
-        lane = lanes[(case // 3) % len(lanes)]
+    for case in range(48):
+        method = ['GMCKF', 'KF', 'IMCCKF', 'MCKF'][case % 4]                   # the four estimators (oracle/c restates all of them)
+        lanes = {'GMCKF': [0, 2, 4, 1, -2], 'KF': [0, 2, 4, -4], 'IMCCKF': [0, 2, 4, -2], 'MCKF': [0, 2, 4, -2, 1, -4]}[method]
+        lane = lanes[(case // 4) % len(lanes)]
         T = int(rng.integers(1, 140))
         K = int(rng.integers(1, 60))
         dt = float(rng.choice([0.02, 0.05, 0.1]))
@@ -42,13 +42,15 @@ def test_random_configurations_match_c_oracle(uvs):
         anneal = bool(rng.random() < 0.4)
         scale = float(rng.choice([0.0, 0.5, 3.0]))
         noise = scale * rng.standard_t(2.5, size=(T, K, 8))
+        thr, cap = float(rng.choice([0.1, 1e-2, 1e-4])), int(rng.choice([1, 2, 5, 1000]))      # MCKF only
         q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
         q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
-        ref = c_oracle.closed_loop_batch(q0, noise, desired, method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True)
-        fp = uvs.engine.make_params(8, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K)
+        ref = c_oracle.closed_loop_batch(q0, noise, desired, method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True,
+                                         fpi_threshold=thr, fpi_epoch_max=cap)
+        fp = uvs.engine.make_params(8, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K, thr, cap)
         out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0)), device='cuda'),
                                      want=('x', 'err', 'q'))
-        tag = (case, method, lane, T, K, dt, gain, bw, anneal, scale)
+        tag = (case, method, lane, T, K, dt, gain, bw, anneal, scale, thr, cap)
         assert np.array_equal(out['status'].cpu().numpy(), ref['status']) and np.array_equal(out['k_done'].cpu().numpy(), ref['k_done']), tag
         ok = ref['status'] == 0
         if not ok.any():

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 CLOSED = golden_names('closed_')                                             # KF / MCKF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
 LANES_86 = (1, 2, 4, -1, -2, -4, 8)      # 1, 2, 4: tuned kernel (closed loop); negative: generic template with |L| lanes
-LANES_CLOSED = LANES_86 + (5,)           # 5: role-split closed-loop kernel (4 estimator lanes per filter + one control lane per trial)
+LANES_CLOSED = LANES_86
 
 
 @pytest.fixture(scope='module')
@@ -249,8 +249,6 @@ def test_estimator_only_replay_fail_semantics(uvs):
 def test_closed_loop_matches_reference(uvs, name, lanes):
     """Whole trial in the kernel (plant + estimator + control) on the reference's noise: trajectories within 1e-8."""
     g = load_golden(name)
-    if lanes == 5 and g['meta']['method'] == 'MCKF':
-        pytest.skip('the role-split variant has no MCKF rows')
     K = len(g['t'])
     fp = _fp(uvs, g, lanes)
     plant = uvs.SyntheticPlant.ur10(g['desired'])
@@ -269,28 +267,6 @@ def test_closed_loop_matches_reference(uvs, name, lanes):
     if name not in CHAOTIC:
         from oracle.rmckf_dense import trial_stats
         assert rel_err(out['stats'].cpu().numpy()[0], trial_stats(g['err'], g['t'])) <= 1e-8
-
-
-@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF'])
-def test_role_split_kernel_on_a_ragged_batch(uvs, method):
-    """lanes_per_filter = 5 (role-split workgroups of 64 trials) on 150 trials = 2 full groups + 22: every trial agrees with the two-lane
-    kernel (different control-law arithmetic: normal equations + refinement vs Householder), trial 0 with the reference fixture, and
-    all optional streams (f, dq, final state) come out."""
-    g = load_golden({'GMCKF': 'closed_gmckf_a1p5', 'KF': 'closed_kf_a1p5', 'IMCCKF': 'closed_imcckf_a1p5'}[method])
-    K, T = 120, 150
-    rng = np.random.default_rng(4)
-    q0 = np.tile(g['q_start'], (T, 1))
-    q0[1:, :2] -= rng.uniform(0.0, 0.3, (T - 1, 2))
-    noise = rng.standard_t(3, size=(K, 8, T))
-    noise[:, :, 0] = g['noise'][:K]
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
-    want = ('x', 'err', 'q', 'f', 'dq')
-    a = uvs.engine.closed_loop(_fp(uvs, g, 5, steps=K), plant.to_struct(), _cuda(q0), _cuda(noise), want=want, final_state=True)
-    b = uvs.engine.closed_loop(_fp(uvs, g, 2, steps=K), plant.to_struct(), _cuda(q0), _cuda(noise), want=want, final_state=True)
-    for key in want + ('stats', 'x_final', 'p_final'):
-        assert rel_err(a[key].cpu().numpy(), b[key].cpu().numpy()) <= 1e-9, key
-    assert np.array_equal(a['status'].cpu().numpy(), b['status'].cpu().numpy()) and np.array_equal(a['k_done'].cpu().numpy(), b['k_done'].cpu().numpy())
-    assert rel_err(a['err'].cpu().numpy()[:, :, 0], g['err'][:K]) <= 1e-8 and rel_err(a['q'].cpu().numpy()[:, :, 0], g['q'][:K]) <= 1e-8
 
 
 def test_initial_guess_matches_reference(uvs):

@@ -36,9 +36,6 @@ inline dim3 grid_for(int64_t T, int L) { return dim3((unsigned)((T * L + 63) / 6
 // tuned closed loop (rmckf_tuned.hpp): method in {KF, IMCCKF, GMCKF}
 bool closed_tuned_a(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 bool closed_tuned_b(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
-// role-split closed loop (rmckf_split.hpp): lanes_per_filter = 5
-bool closed_split(int m, int n, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
-constexpr int kSplitLanes = 5;
 // tuned wide-shape closed loop (rmckf_wide.hpp): (32,7), lanes_per_filter = 8 (the default of that shape for the closed loop)
 bool closed_wide(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 // generic templates (rmckf_generic.hpp)

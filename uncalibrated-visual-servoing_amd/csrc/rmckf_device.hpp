@@ -261,7 +261,9 @@ struct Rows {
             ap[r] = a;
             const double cy = gaussian_kernel(nu0[r], sigma);                    // first pass: Xc = X
             bad |= (cy == 0.0);
-            const double gain = 1.0 / (a + 1.0 / cy);
+            // a subnormal weight whose reciprocal overflows (cy <= 2^-1024): inv(Cy) = inf, 0 * inf = NaN in the reference's dense
+            // Br @ inv(Cy) @ Br.T (:232) -- the gain is NaN, the state follows and the trial FAILs (see kRcpOverflowsAtOrBelow, rmckf_tuned.hpp)
+            const double gain = (cy <= 0x1p-1024) ? __builtin_nan("") : 1.0 / (a + 1.0 / cy);
 #pragma unroll
             for (int l = 0; l < N; ++l) {
                 kk[r][l] = gp[r][l] * gain;
@@ -331,7 +333,7 @@ struct Rows {
                         g[i] = s;
                         a = fma(h[i], s, a);
                     }
-                    const double gain = 1.0 / (a + 1.0 / cy);
+                    const double gain = (cy <= 0x1p-1024) ? __builtin_nan("") : 1.0 / (a + 1.0 / cy);
 #pragma unroll
                     for (int l = 0; l < N; ++l) {
                         kn[r][l] = g[l] * gain;
@@ -479,7 +481,7 @@ UVS_DEV void svd_solve(double (&A)[N][N], const double (&c)[N], double (&sol)[N]
     }
 }
 
-// ---------------------------------------------------------------- normal equations (role-split and wide-shape kernels)
+// ---------------------------------------------------------------- normal equations (wide-shape kernel, control-law wavefronts of the replay)
 // G = J^T J = L L^T.  The pivots of the Cholesky factor are the R_cc^2 of the QR of J, so the same spread test marks ill-conditioned
 // Jacobians for the careful second pass -- here already from a spread of 2^20 in |R_cc|, because the error of the normal equations
 // grows with cond(J)^2 (one refinement step squares it again: measured against numpy's pinv 5e-14 relative at cond <= 1.5e3, the same

@@ -220,9 +220,8 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
 
 namespace uvs {
 
-// One trial per lane, everything in registers: sol = pinv(J) y by the normal equations with one refinement step (the solver of
-// rmckf_split.hpp, which streams J from LDS because its wavefront also carries covariance blocks; a control wavefront of the replay
-// carries nothing else).  Split in two halves so that a workgroup barrier can sit between them.
+// One trial per lane, everything in registers: sol = pinv(J) y by the normal equations with one refinement step (a control wavefront of
+// the replay carries nothing but the panel).  Split in two halves so that a workgroup barrier can sit between them.
 template <int M, int N>
 UVS_DEV void normal_eq_gram(const double (&x)[M][N], const double (&y)[M], double (&G)[Sym<N>::NP], double (&b)[N]) {
 #pragma unroll
@@ -292,7 +291,7 @@ UVS_DEV double blocked_sum(double v) {
 // estimator wavefronts only drop X_k, kappa o err and their finiteness probe into a double-buffered LDS block and meet the control
 // wavefronts at one barrier per step; control wavefront c takes the steps k = c (mod 2) and has two barrier intervals for each (Gram
 // matrix in the first, Cholesky + solve + refinement + stores in the second).  Normal equations: ill-conditioned Jacobians are marked
-// for the careful second pass exactly as in the role-split closed-loop kernel.
+// for the careful second pass exactly as in the closed-loop kernels.
 template <int M, int N, int L, int METHOD, bool XOUT, bool EOUT, bool BYWAVE = false, bool REC = false, int CW = 0>
 __global__ __launch_bounds__(BYWAVE ? 64 * (L + CW) : 64, 2) void replay_rows_kernel(const ReplayArgs A) {
     static_assert((L == 2 || L == 4) && M % L == 0, "rows kernel: 2 or 4 lanes per filter");

@@ -119,6 +119,13 @@ struct FpiProbe {
 };
 // exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.13321910194...; between the two bounds the kernels do not decide themselves
 constexpr double kExpZeroBelow = -745.14, kExpNonzeroAbove = -745.13;
+// A weight that is subnormal but not 0 -- at most 2^-1024, so that its reciprocal overflows -- does not make inv(Cy) raise: it returns inf,
+// the reference's dense product Br @ inv(Cy) @ Br.T (experiment.py:232) turns 0 * inf into NaN, and the gain, the state and the trial are
+// lost (pinv raises in the control law, :312-316: ExperimentStatus.FAIL at this step).  With Cauchy-like noise and the reference's shipped
+// parameters that is how ~7 % of its alpha = 1 trials end (innovations between 37.7 and 38.6 sigma; fixtures tests/golden/fpi_*_fail,
+// fpi_default_*).  The kernels reproduce it by poisoning the gain of the row.
+constexpr double kRcpOverflowsAtOrBelow = 0x1p-1024;
+UVS_DEV double mckf_poison(double gain, double cy) { return (cy <= kRcpOverflowsAtOrBelow) ? __builtin_nan("") : gain; }
 
 // Pre-pass of an MCKF step over the lane's rows: innovation of every row against the prior state, to find out whether some Cy is
 // exactly 0 -- inv(Cy) then raises in the reference and the step keeps only the prediction (experiment.py:225-236; with Cauchy-like noise
@@ -226,7 +233,7 @@ UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::N
         g[i] = v;
         a = fma(h[i], v, a);
     }
-    const double gain = cy * fast_rcp(fma(a, cy, 1.0));
+    const double gain = mckf_poison(cy * fast_rcp(fma(a, cy, 1.0)), cy);     // cy == 0 is `bad` (the caller skips the correction), not poison
 #pragma unroll
     for (int l = 0; l < N; ++l) {
         kn[l] = g[l] * gain;
@@ -331,7 +338,7 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         // first fixed-point pass: Xc = X, so Cx = I and P_hat = P; gain = 1 / (a + 1 / Cy) (experiment.py:225-242).  The state update
         // and the Joseph form below are then exactly those of the other estimators; kappa of the control law is 1 (:303-308)
         const double cy = exp_nonpos((nu * nu) * neg_half_inv_s2);
-        gamma = fpi.skip ? 0.0 : cy * fast_rcp(fma(a, cy, 1.0));  // skipped correction: X stays, P keeps the prediction (gamma = 0 below)
+        gamma = fpi.skip ? 0.0 : mckf_poison(cy * fast_rcp(fma(a, cy, 1.0)), cy);  // skipped correction: X stays, P keeps the prediction (gamma = 0 below)
         kap = 1.0;
         double gg = 0.0;
 #pragma unroll

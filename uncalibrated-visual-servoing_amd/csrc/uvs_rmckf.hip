@@ -69,7 +69,6 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap) {
 #define X(M, N, L) if (m == M && n == N) { if (lanes && cnt < cap) lanes[cnt] = L; ++cnt; }
     UVS_SHAPES(X)
 #undef X
-    if (m == 8 && n == 6) { if (lanes && cnt < cap) lanes[cnt] = kSplitLanes; ++cnt; }     // role-split closed-loop kernel
     return cnt;
 }
 
@@ -107,7 +106,6 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
                            (fp->method == UVS_METHOD_MCKF && L == 2)) && fp->lanes_per_filter >= 0;
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
-    if (tuned_ok && L == kSplitLanes) launched = closed_split(fp->m, fp->n, fp->method, linear, xo, T, s, A);
     if (!launched && tuned_ok) launched = closed_wide(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched && tuned_ok) launched = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);

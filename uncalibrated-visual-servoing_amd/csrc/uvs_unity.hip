@@ -17,7 +17,6 @@
 #undef UVS_TU_CLOSED_CAREFUL
 #undef UVS_TU_REPLAY_CAREFUL
 #include "tu_careful_b.hip"
-#include "tu_closed_split.hip"
 #include "tu_closed_wide.hip"
 #include "tu_replay_tuned.hip"
 #include "tu_misc.hip"
