@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -254,3 +255,26 @@ def test_camera_pose_matches_quat2euler_convention():
     robot = uvs_amd.SyntheticRobot(plant)
     robot.start([0.1, -0.2, 1.9, 0.0, -1.5, 0.3])
     assert np.allclose(robot.computePose(), uvs_amd.plant.camera_pose(plant.fkine_all(robot.q)[-1]))
+
+
+def test_default_kernels_have_no_scratch():
+    """The register-bound closed-loop kernels live or die by their allocation (a scratch round trip in the step loop once cost the MCKF
+    instantiation 20 %): the library-default (8,6) two-lane instantiations of every estimator, the wide-shape kernel's RMCKF / KF record
+    variants and the default replay mappings must not carry a private segment.  Read from the code objects embedded in the built .so."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_resources
+    if not os.path.exists(kernel_resources.READELF):
+        pytest.skip('llvm-readelf not available')
+    k = kernel_resources.kernels()
+    assert len(k) > 100
+    for method in (2, 3, 4, 5):                                              # KF, MCKF, IMCCKF, GMCKF
+        for plant in (0, 1):
+            for xout in ('true', 'false'):
+                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}>']
+                assert r['scratch'] == 0 and r['vgpr'] <= 512, (method, plant, xout, r)
+                # KF / IMCC-KF keep one covariance block per lane and must fit two wavefronts per SIMD (256 registers, 8 x 19 KB of LDS per CU)
+                if method in (2, 4):
+                    assert r['vgpr'] <= 256 and r['lds'] <= 20480, (method, r)
+    for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true>',
+                 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
+        assert k[name]['scratch'] == 0, (name, k[name])

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
             });
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
             fpi.unsure = pair_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0;
+            fpi.poison = (pair_sum<L>(fpi.poison ? 1.0 : 0.0) != 0.0) && fp.fpi_epoch_max > 1;    // (a cap of one pass goes to the careful pass anyway)
         }
         double *pxr = px;
 #pragma unroll
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(64) void replay_tuned_kernel(const ReplayArgs A) {
         if constexpr (XOUT) px += A.x_out.sk;
         asm volatile("" ::: "memory");                           // LDS is the only copy of X from here on
         chk = pair_sum<L>(chk);
+        if constexpr (METHOD == UVS_METHOD_MCKF) chk = mckf_poisoned(fpi, chk);
         if (alive && !(chk == 0.0)) {                            // pinv would raise (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(BYWAVE ? 64 * (L + CW) : 64, 2) void replay_rows_ke
             });
             fpi.skip = blocked_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;
             fpi.unsure = blocked_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0;
+            fpi.poison = (blocked_sum<L>(fpi.poison ? 1.0 : 0.0) != 0.0) && fp.fpi_epoch_max > 1;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -508,6 +511,7 @@ __global__ __launch_bounds__(BYWAVE ? 64 * (L + CW) : 64, 2) void replay_rows_ke
         if constexpr (XOUT) px += A.x_out.sk;
         if constexpr (EOUT) pe += A.err_out.sk;
         if constexpr (!BYWAVE) chk = blocked_sum<L>(chk);
+        if constexpr (METHOD == UVS_METHOD_MCKF) chk = mckf_poisoned(fpi, chk);
         if (alive && !(chk == 0.0)) {
             alive = false;
             status = UVS_STATUS_FAIL;

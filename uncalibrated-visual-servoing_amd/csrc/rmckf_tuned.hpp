@@ -114,6 +114,7 @@ UVS_DEV double pick_sub(const double *v, int sub) {
 struct FpiProbe {
     double num = 0.0, den = 0.0;                                 // num = +inf: not decidable here, leave the trial to the careful pass
     bool skip = false;                                           // a weight Cy underflowed to 0: the whole correction of this step is skipped
+    bool poison = false;                                         // a weight of one of the lane's rows is subnormal: NaN gain, the trial FAILs
     bool unsure = false;                                         // ... or sits so close to the underflow that only the careful pass may decide
     double row_gamma = 0.0, row_a = 0.0, row_nu = 0.0;           // first-pass gain, h.P h and innovation of the row just processed
 };
@@ -125,6 +126,7 @@ constexpr double kExpZeroBelow = -745.14, kExpNonzeroAbove = -745.13;
 // parameters that is how ~7 % of its alpha = 1 trials end (innovations between 37.7 and 38.6 sigma; fixtures tests/golden/fpi_*_fail,
 // fpi_default_*).  The kernels reproduce it by poisoning the gain of the row.
 constexpr double kRcpOverflowsAtOrBelow = 0x1p-1024;
+constexpr double kRcpOverflowArg = -709.78271289338397;          // ln(2^-1024): the same boundary on the argument of the exponential
 UVS_DEV double mckf_poison(double gain, double cy) { return (cy <= kRcpOverflowsAtOrBelow) ? __builtin_nan("") : gain; }
 
 // Pre-pass of an MCKF step over the lane's rows: innovation of every row against the prior state, to find out whether some Cy is
@@ -132,16 +134,23 @@ UVS_DEV double mckf_poison(double gain, double cy) { return (cy <= kRcpOverflows
 // that is 1-2 % of the steps, it is not an exotic path).  `probe(r)` returns nu_r^2 * (-1 / (2 sigma^2)), the argument of the weight.
 template <int R, typename ArgOfRow>
 UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
-    bool zero = false, unsure = false;
+    bool zero = false, unsure = false, poison = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double a = arg_of_row(r);
         zero |= a < kExpZeroBelow;
         unsure |= !(a < kExpZeroBelow) && !(a > kExpNonzeroAbove);    // NaN lands here as well; the finiteness probe FAILs the trial anyway
+        poison |= a < kRcpOverflowArg;                                // decided on the argument: no weight has to stay live for it
     }
     fpi.skip = zero;
     fpi.unsure = unsure;
+    fpi.poison = poison;                                              // (a zero weight anywhere in the filter wins: inv(Cy) raises first)
 }
+// The reference's NaN state after a subnormal weight (see kRcpOverflowsAtOrBelow), applied to the finiteness probe of the step: the trial
+// FAILs at this step exactly as if its X had turned NaN; what the rows computed instead (a gain of ~0) lands in rows at and after k_done,
+// which are unspecified.  skip and poison must already be filter-wide (summed over the lanes of the filter).
+UVS_DEV double mckf_poisoned(const FpiProbe &f, double chk) { return (f.poison && !f.skip) ? __builtin_nan("") : chk; }
+
 // Verdict after the rows of a step (num / den summed over the lanes of the filter): true when the first pass is not the whole story --
 // a second fixed-point pass would run, the correction would be skipped, or the test is too close to call in different rounding.  The
 // tuned kernels then mark the trial and the careful second pass (generic template, full fixed-point iteration) redoes it.  On the
@@ -338,7 +347,9 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         // first fixed-point pass: Xc = X, so Cx = I and P_hat = P; gain = 1 / (a + 1 / Cy) (experiment.py:225-242).  The state update
         // and the Joseph form below are then exactly those of the other estimators; kappa of the control law is 1 (:303-308)
         const double cy = exp_nonpos((nu * nu) * neg_half_inv_s2);
-        gamma = fpi.skip ? 0.0 : mckf_poison(cy * fast_rcp(fma(a, cy, 1.0)), cy);  // skipped correction: X stays, P keeps the prediction (gamma = 0 below)
+        // skipped correction: X stays, P keeps the prediction (gamma = 0 below).  (A subnormal weight -- fpi.poison -- is not injected here:
+        // a select on the gain costs this register-bound kernel 108 B of scratch; the caller FAILs the trial through mckf_poisoned.)
+        gamma = fpi.skip ? 0.0 : cy * fast_rcp(fma(a, cy, 1.0));
         kap = 1.0;
         double gg = 0.0;
 #pragma unroll
@@ -524,10 +535,23 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     asm volatile("" ::"v"(&lds_pad[threadIdx.x]) : "memory");
 #endif
 
+#ifdef UVS_WAVE_TIMES                   // diagnostic build: when and where did this wavefront run (100 MHz wall clock, HW_ID, XCC_ID)
+    unsigned long long wt_first;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
+#endif
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
     const int grp = SPLIT ? (sub < G ? sub : G - 1) : 0;           // with L = 4 the fourth lane mirrors group 2
+#ifdef UVS_WAVE_TIMES                   // experiment: workgroup -> trial-chunk mappings (A.fp.reserved selects; 0 = identity)
+    long long chunk = blockIdx.x;
+    {
+        const long long nw = gridDim.x, nfull = (nw / 8) * 8;
+        if (A.fp.reserved == 1 && chunk < nfull) chunk = (chunk % 8) * (nfull / 8) + chunk / 8;      // XCD x owns a contiguous eighth of the trials
+    }
+    const long long wave_first = chunk * TPW;
+#else
     const long long wave_first = (long long)blockIdx.x * TPW;      // first trial of this wavefront (uniform)
+#endif
     const unsigned tl = lane / L;                                   // trial within the wavefront
     const bool valid = wave_first + tl < A.T;
     const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
@@ -809,6 +833,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             });
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;  // one underflowed weight anywhere in the filter skips every row's correction
             fpi.skip |= fp.fpi_epoch_max <= 1;                    // "reached max epoch" after the only pass: correction skipped (:246-250)
+            fpi.poison = pair_sum<L>(fpi.poison ? 1.0 : 0.0) != 0.0;
             flagged |= alive && (pair_sum<L>(fpi.unsure ? 1.0 : 0.0) != 0.0);
         }
         double m_gamma[R], m_a[R], m_nu[R], m_z[R];              // MCKF: what the undo of a row needs (dead code for the other estimators)
@@ -869,7 +894,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             fpi.den = pair_sum<L>(fpi.den);
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
             int it = 1;
-            bool more = alive && !fpi.skip && (fpi.num > thr2 * fpi.den);        // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
+            bool more = alive && !fpi.skip && !fpi.poison && (fpi.num > thr2 * fpi.den);  // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
             if (__any(more)) {
                 const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
                 bool skip2 = false;
@@ -951,6 +976,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             }
         }
         chk = pair_sum<L>(chk);
+        if constexpr (METHOD == UVS_METHOD_MCKF) chk = mckf_poisoned(fpi, chk);
         if (alive && !(chk == 0.0)) {                            // pinv would raise (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -1060,6 +1086,19 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) A.stats[3 * trial + c] = sqrt(s2[c]);
         }
+#ifdef UVS_WAVE_TIMES
+        if (lane == 0 && A.stats) {                             // overwrites the statistics of the wavefront's first two trials
+            unsigned long long wt_last;
+            unsigned hw_id, xcc_id;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_last)::"memory");
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            A.stats[3 * wave_first + 0] = (double)wt_first;
+            A.stats[3 * wave_first + 1] = (double)wt_last;
+            A.stats[3 * wave_first + 2] = (double)hw_id;
+            A.stats[3 * wave_first + 3] = (double)xcc_id;
+        }
+#endif
         if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
         if (A.k_done) A.k_done[trial] = k_done;
     }
