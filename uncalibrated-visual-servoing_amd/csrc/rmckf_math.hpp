@@ -111,6 +111,30 @@ UVS_DEV void sincos_bounded(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// Rotation of a tracked (sin, cos) pair by a small angle d, |d| <= kSinCosStepMax: sin(t + d), cos(t + d) from the addition theorems
+// with Taylor polynomials in d (truncation < 3e-18 relative at the bound) -- 17 instructions against the 47 of sincos_bounded.  Each
+// application adds ~1 ulp of rounding to the pair, so callers re-seed it from the angle itself every kSinCosResync steps.
+constexpr double kSinCosStepMax = 0.1;
+constexpr int kSinCosResync = 16;
+UVS_DEV void sincos_advance(double &s, double &c, double d) {
+    const double z = d * d;
+    double ps = 2.7557319223985893e-06;                    // 1/9!
+    ps = fma(ps, z, -1.984126984126984e-04);               // -1/7!
+    ps = fma(ps, z, 8.333333333333333e-03);                // 1/5!
+    ps = fma(ps, z, -1.6666666666666666e-01);              // -1/3!
+    const double sd = fma(d * z, ps, d);                   // sin d
+    double pc = -2.755731922398589e-07;                    // -1/10!
+    pc = fma(pc, z, 2.48015873015873e-05);                 // 1/8!
+    pc = fma(pc, z, -1.388888888888889e-03);               // -1/6!
+    pc = fma(pc, z, 4.166666666666666e-02);                // 1/4!
+    pc = fma(pc, z, -0.5);
+    const double m = z * pc;                               // cos d - 1
+    const double s1 = s + fma(s, m, c * sd);
+    const double c1 = c + fma(c, m, -(s * sd));
+    s = s1;
+    c = c1;
+}
+
 // Range at which sincos_bounded hands over to the library routine (exact huge-argument reduction).
 constexpr double kSinCosBoundedMax = 1.0e5;
 

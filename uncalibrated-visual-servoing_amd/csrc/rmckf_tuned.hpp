@@ -507,6 +507,9 @@ struct PlantLds {
 // With L = 4 the whole state fits the 256 VALU-addressable registers (P: 84, X: 24), LDS holds only the statistics and
 // the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
 // issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
+#ifndef UVS_INC_SINCOS                  // experiment builds: 0 = sincos of every joint angle from scratch every step (round-2 code)
+#define UVS_INC_SINCOS 1
+#endif
 #ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 #define UVS_SHARED_OCC 2
 #endif
@@ -586,6 +589,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     }
 
     double q[JG], dq[N], f_prev[R], des[R];                        // q: this lane's joints; dq: replicated command
+    double sn[JG], cs[JG];                                         // sin / cos of this lane's joint angles, carried from step to step
+    bool reseed = true;
+#pragma unroll
+    for (int u = 0; u < JG; ++u) { sn[u] = 0.0; cs[u] = 1.0; }
     double p[PV > 0 ? PV : 1][NP];
     double xr[XREG ? R : 1][N];                                    // X when it lives in registers
     {
@@ -699,21 +706,37 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 z[r] = acc;
             }
         } else {
-            // joint angles of this lane's links; one range test per step decides between the bounded sincos and the library routine
+            // sines / cosines of this lane's joint angles.  The joints move by dq * dt per step, so the pair of a joint is carried from step
+            // to step by the addition theorems (sincos_advance at the end of the step, 17 instructions per joint) and re-seeded from the
+            // angle itself every kSinCosResync steps, or at once when some lane's step was too large for the polynomials (or not finite).
             const double *cj = &lds_c[PC::kJoint + 5 * JG * grp];
-            double th[JG], sn[JG], cs[JG];
-            bool big = false;
+            // Whether a lane re-seeds, and from which routine, is decided per lane (the wavefront only shares the branch): a trial's
+            // results do not depend on its neighbours in the batch.
+            const bool need = !UVS_INC_SINCOS || reseed || (k & (kSinCosResync - 1)) == 0;
+            if (__any(need)) {
+                double th[JG], s_new[JG], c_new[JG];
+                bool big = false;
 #pragma unroll
-            for (int u = 0; u < JG; ++u) {
-                th[u] = q[u] + cj[5 * u];
-                big |= !(fabs(th[u]) <= kSinCosBoundedMax);
-            }
-            if (__builtin_expect(__any(big), 0)) {
+                for (int u = 0; u < JG; ++u) {
+                    th[u] = q[u] + cj[5 * u];
+                    big |= !(fabs(th[u]) <= kSinCosBoundedMax);
+                    sincos_bounded(th[u], s_new[u], c_new[u]);
+                }
+                if (__builtin_expect(__any(need && big), 0)) {      // beyond the bounded routine's range (or not finite): the library's reduction
 #pragma unroll
-                for (int u = 0; u < JG; ++u) sincos(th[u], &sn[u], &cs[u]);
-            } else {
+                    for (int u = 0; u < JG; ++u) {
+                        double sl, cl;
+                        sincos(th[u], &sl, &cl);
+                        s_new[u] = big ? sl : s_new[u];
+                        c_new[u] = big ? cl : c_new[u];
+                    }
+                }
 #pragma unroll
-                for (int u = 0; u < JG; ++u) sincos_bounded(th[u], sn[u], cs[u]);
+                for (int u = 0; u < JG; ++u) {
+                    sn[u] = need ? s_new[u] : sn[u];
+                    cs[u] = need ? c_new[u] : cs[u];
+                }
+                reseed = false;
             }
             double T[3][4];                                 // product of this lane's links (the whole chain when !SPLIT)
 #pragma unroll
@@ -1053,6 +1076,14 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             lds_acc[2 * R + r][lane] = fma(t, ae, acc_now[2 * R + r]);
         }
         UVS_STAMP(3);                                            // logs + statistics
+        if constexpr (UVS_INC_SINCOS && PLANT == UVS_PLANT_DH_PINHOLE) {
+#pragma unroll
+            for (int u = 0; u < JG; ++u) {
+                const double d = dq_own[u] * fp.dt;
+                reseed |= !(fabs(d) <= kSinCosStepMax);             // too large for the polynomials, or not finite: re-seed at the next step
+                sincos_advance(sn[u], cs[u], d);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < JG; ++u) q[u] = fma(dq_own[u], fp.dt, q[u]);       // new_q = q + dq t_s (experiment.py:320)
         t += fp.dt;
