@@ -7,9 +7,13 @@ A *step* is one pass of the hot path over one batch: the closed-loop kernel adva
 config 2 (4 features / 6 DoF, GMCKF = RMCKF, sigma 10, alpha-stable noise alpha = 1.5, 65 536 trials, 299 filter
 updates per trial) from q_start to the end of the trial, with the noise streams already resident in HBM and the
 per-step X / error / joint logs written to HBM.  One *update* = predict + correntropy-weighted correct + control law of
-one filter for one time step.  With N > 1 every rank runs its own 65 536 trials (global trial indices
-rank*65536 ..., so seeds differ) -- weak scaling, no data-path collective -- followed by one RCCL all-gather of the
-per-trial [ISE, IAE, ITAE, status] rows, which is inside the timed region.
+one filter for one time step.
+
+Multi-GPU (one process per GPU under torch.distributed.run): trials are enumerated globally (main.py:121-139: seed0 + t, t-th jitter
+draw) and rank r owns the contiguous shard dist.shard_range(total, r, N) -- no data-path collective -- followed by one RCCL all-gather
+of the per-trial [ISE, IAE, ITAE, status] rows, which is inside the timed region.  --scaling strong (default: north_star's series, "a
+65 536-trial batch at 1, 2, 4 and 8 MI355X") keeps the TOTAL at the config's size, --scaling weak gives every GPU the config's size;
+--config 4 is BASELINE config 4: 1 048 576 trials in total over however many ranks there are.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
 """
@@ -272,19 +276,115 @@ def side_config(config, torch, uvs_amd, engine, batch, dev, trials=None, reps=5,
     return out
 
 
+CONFIG_TRIALS = {2: TRIALS_PER_GPU, 3: 262144, 4: 1048576, 5: TRIALS_PER_GPU}
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4        # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at the 2.4 GHz peak clock
+FP64_VECTOR_PEAK_FLOPS = 78.6e12                     # MI355X_MICROARCH.md: fp64 vector peak
+
+
+def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU):
+    """What main.py:104-196 does for one sweep, end to end on the GPU (side object, never `value`): for each of the reference's 12 cells
+    alpha = linspace(1, 2, 12) -- device seeding + noise generation, closed loop with X / err / q logged, D2H of the per-trial
+    [ISE, IAE, ITAE, status, k_done] rows -- at `trials_per_cell` trials per cell.  Timed twice: cell after cell on one stream, and with
+    the noise of cell c + 1 generated on a second stream while the closed loop of cell c runs."""
+    import ctypes as C
+    cfg = config2()
+    cfg['experiments']['epoch'] = trials_per_cell
+    plan = batch.plan_trials(cfg)                                  # 12 cells x trials_per_cell, global seeds / jitter draws
+    cells = plan.cells
+    T, K, M, N = trials_per_cell, len(engine.loop_clock(0.05, 15)), 8, 6
+    fp = engine.make_params(M, N, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    NV = uvs_amd._lib.NULL_VIEW
+    flat = lambda t: uvs_amd._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))     # noqa: E731
+    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev) for k, c in (('x', M * N), ('err', M), ('q', N))}
+    noise = [engine.alloc_stream(T, K, M, 'kct', dev) for _ in range(2)]
+    rows_dev = [torch.zeros((T, 5), dtype=torch.float64, device=dev) for _ in range(2)]
+    rows_host = torch.empty((len(cells), T, 5), dtype=torch.float64).pin_memory()
+    stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    k_done = torch.zeros(T, dtype=torch.int32, device=dev)
+    q0_all = torch.as_tensor(plan.q_start.copy(), device=dev)
+    nt = uvs_amd.NoiseType.ALPHA_STABLE
+
+    def gen(c, buf):
+        params = dict(alpha=float(cells[c]), beta=0, gamma=1, delta=0)
+        uvs_amd.noise_device.generate(nt, params, plan.seed[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
+
+    def loop(c, buf, slot):
+        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
+            C.byref(fp), C.byref(plant), T, flat(q0_all[c * T:(c + 1) * T]), engine.stream_view(buf, 'kct'), NV,
+            engine.stream_view(bufs['x'], 'kct'), engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'), NV, NV,
+            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        uvs_amd._lib.check(rc)
+        r = rows_dev[slot]
+        r[:, :3] = stats
+        r[:, 3] = status
+        r[:, 4] = k_done
+        rows_host[c].copy_(r, non_blocking=True)
+
+    def serial():
+        for c in range(len(cells)):
+            gen(c, noise[0])
+            loop(c, noise[0], 0)
+        torch.cuda.synchronize()
+
+    side = torch.cuda.Stream(device=dev)
+
+    def overlapped():
+        main = torch.cuda.current_stream()
+        ready = [torch.cuda.Event() for _ in cells]
+        freed = [torch.cuda.Event() for _ in cells]
+        for c in range(len(cells)):
+            with torch.cuda.stream(side):
+                if c >= 2:
+                    side.wait_event(freed[c - 2])                  # the buffer's previous cell has been consumed
+                gen(c, noise[c % 2])
+                ready[c].record(side)
+            main.wait_event(ready[c])
+            loop(c, noise[c % 2], c % 2)
+            freed[c].record(main)
+        torch.cuda.synchronize()
+
+    out = {}
+    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped)):
+        fn()                                                       # warm-up (allocator, tables)
+        t0 = time.perf_counter()
+        fn()
+        wall = time.perf_counter() - t0
+        rows = rows_host.numpy()
+        updates = int(rows[:, :, 4].sum())
+        out[name] = {'wall_ms': wall * 1e3, 'ms_per_cell': wall * 1e3 / len(cells), 'updates_per_s': updates / wall, 'failed_trials': int((rows[:, :, 3] != 0).sum())}
+    # the pieces on their own (events on one stream), for the breakdown
+    ev = lambda: torch.cuda.Event(enable_timing=True)             # noqa: E731
+    a, b, c_, d = ev(), ev(), ev(), ev()
+    a.record(); gen(5, noise[0]); b.record(); loop(5, noise[0], 0); c_.record()
+    torch.cuda.synchronize()
+    out['breakdown_one_cell_ms'] = {'seeding_and_noise_generation': a.elapsed_time(b), 'closed_loop_kernel_and_row_copy': b.elapsed_time(c_)}
+    out.update(workload=f'the reference sweep of main.py:104-148: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), X+err+q logged on the device, '
+                        'per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory', cells=len(cells), trials_per_cell=T, updates_total=updates,
+               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell; never part of `value`')
+    del bufs, noise
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 5], help='BASELINE.json config: 2 (headline), 3 (mixture + annealing, 262144 trials), 5 (16-feature / 7-DoF stress)')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5],
+                    help='BASELINE.json config: 2 (headline, 65 536 trials), 3 (mixture + annealing, 262 144), 4 (config-2 inputs, 1 048 576 trials in total over all ranks), 5 (16-feature / 7-DoF stress)')
+    ap.add_argument('--scaling', default=None, choices=['strong', 'weak'],
+                    help="strong (default): the config's trial count is the TOTAL, sharded over the ranks (north_star's 65 536-trial series); weak: every GPU runs the config's trial count")
     ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
-    ap.add_argument('--trials', type=int, default=0, help='trials per GPU (default: the size BASELINE.json names for the config)')
+    ap.add_argument('--trials', type=int, default=0, help="override the config's trial count (total for strong, per GPU for weak)")
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
     ap.add_argument('--no-replay', action='store_true', help='skip the replay-mode (estimator kernel) side measurement')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-rank code path (process group, barrier, stats gather) even with one rank: RCCL smoke test on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-side', action='store_true', help='skip the config 3 / config 5 side measurements of the default run')
+    ap.add_argument('--no-side', action='store_true', help='skip the side measurements of the default run (configs 3 / 3-hold / 5, other estimators, end-to-end sweep)')
+    ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
@@ -298,29 +398,33 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
     dist_on = world > 1 or args.force_dist
+    scaling = args.scaling or 'strong'
+    assert not (args.config == 4 and scaling == 'weak'), 'config 4 names a TOTAL (1 048 576 trials over all ranks): it has no weak form'
 
     import uvs_amd
     from uvs_amd import batch, dist, engine
 
     cfg = config2()
-    if args.trials == 0:
-        args.trials = 262144 if args.config == 3 else TRIALS_PER_GPU
+    size = args.trials or CONFIG_TRIALS[args.config]
+    trials_total = size * world if scaling == 'weak' else size
+    assert trials_total >= world, 'fewer trials than ranks'
     cell = ALPHA
     if args.config == 3:                                          # BASELINE config 3 / BASELINE.md table
         cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0, 'rho': 0.1}, hold=bool(args.hold), hold_time=0.5)
         cfg['estimator']['estimator_params']['annealing'] = True
         cell = 0.1
-    cfg['experiments']['epoch'] = args.trials * world
-    plan = batch.plan_trials(cfg, cells=[cell])                   # global enumeration: trial t -> seed 123456 + t, jitter draw t
+    cfg['experiments']['epoch'] = trials_total
+    plan = batch.plan_trials(cfg, cells=[cell])                   # global enumeration: trial t -> seed 123456 + t, jitter draw t (main.py:121-139)
     lo, hi = dist.shard_range(len(plan), rank, world)
     t_log = engine.loop_clock(0.05, 15)
     K = len(t_log)
+    headline_shape = args.config == 2 and hi - lo == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2) and not args.stats_only
 
     # ---- everything that forks happens before the GPU is touched
     cores = available_cores()
     workers = max(1, cores // max(1, world))
     cpu = None
-    assert not (args.host_noise and args.config != 2), '--host-noise is wired for config 2 only'
+    assert not (args.host_noise and args.config not in (2, 4)), '--host-noise is wired for the config-2 inputs only'
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         cpu = cpu_baseline(plan.q_start)
     noise_host, gen_s = None, 0.0
@@ -339,6 +443,7 @@ def main():
             td.init_process_group('nccl', device_id=dev)         # RCCL over xGMI
         else:
             td.init_process_group('gloo')
+    ranks_seen = td.get_world_size() if dist_on else 1
     uvs_amd.lib()
 
     t0 = time.perf_counter()
@@ -399,70 +504,91 @@ def main():
         rows = dist.pack_rows(stats, status)
         return dist.gather_trial_rows(rows if args.backend == 'nccl' else rows.cpu(), len(plan))
 
-    def one_step():
-        launch()
-        return gather() if dist_on else None
-
     def barrier():
         if dist_on:
             td.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step()
+        launch()
+        if dist_on:
+            gather()
     barrier()
-    kernel_ms = []
+    kernel_ev, gather_host_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()                                               # HIP events on the stream the kernel is launched on
         launch()
         e1.record()
         if dist_on:
+            g0 = time.perf_counter()
             gathered = gather()
-        kernel_ms.append((e0, e1))
+            gather_host_ms.append((time.perf_counter() - g0) * 1e3)   # gloo: host-side; nccl: enqueue time only, see the events
+        e2.record()
+        kernel_ev.append((e0, e1, e2))
     barrier()
     wall = time.perf_counter() - t0
     red_dev = dev if args.backend == 'nccl' else torch.device('cpu')
+    kernel_ms = [a.elapsed_time(b) for a, b, _ in kernel_ev]
+    gather_ms = [b.elapsed_time(c) for _, b, c in kernel_ev] if args.backend == 'nccl' else gather_host_ms
+    avg_ms = float(np.mean(kernel_ms))
+    rank_ms = {'max': avg_ms, 'min': avg_ms}
+    gather_avg = float(np.mean(gather_ms)) if dist_on else 0.0
     if dist_on:
-        w = torch.tensor([wall], dtype=torch.float64, device=red_dev)
+        w = torch.tensor([wall, avg_ms, -avg_ms, gather_avg], dtype=torch.float64, device=red_dev)
         td.all_reduce(w, op=td.ReduceOp.MAX)
-        wall = float(w.item())
+        wall, rank_ms, gather_avg = float(w[0]), {'max': float(w[1]), 'min': -float(w[2])}, float(w[3])
         assert gathered.shape == (len(plan), 4)
-    kernel_ms = [a.elapsed_time(b) for a, b in kernel_ms]
 
     updates_per_launch = int(k_done.sum().item())                 # FAIL trials stop early; count what was actually computed
+    failed_local = int((status != 0).sum().item())                # of THIS workload: the side measurements below re-use the status buffer
     if dist_on:
-        u = torch.tensor([updates_per_launch], dtype=torch.int64, device=red_dev)
+        u = torch.tensor([updates_per_launch, failed_local], dtype=torch.int64, device=red_dev)
         td.all_reduce(u)
-        total_updates = int(u.item())
+        total_updates, failed_total = int(u[0]), int(u[1])
     else:
-        total_updates = updates_per_launch
+        total_updates, failed_total = updates_per_launch, failed_local
     value = total_updates * args.steps / wall
 
     if rank == 0:
         b_alg = 8 * (2 * M + N + M * N)                           # 560 B / update at (8,6): noise in, err + X + q out
         if args.stats_only:
             b_alg = 8 * M                                         # only the noise stream is read; statistics are 24 B per trial
-        avg_ms = float(np.mean(kernel_ms))
         achieved = updates_per_launch * b_alg / (avg_ms * 1e-3) / 1e9
-        traffic, tr_src = None, None
+        traffic, tr_src, valu = None, None, None
         tr_path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tr_path) and args.config == 2 and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2) and not args.stats_only:
+        if os.path.exists(tr_path) and headline_shape:
             tr = json.load(open(tr_path))
             traffic = tr.get('hbm_bytes_per_launch')                # rocprofv3 PMC, measured on exactly this launch shape -- a committed
             tr_src = f"profiles/traffic_latest.json (round {tr.get('round')}, {tr.get('source')}): rocprofv3 PMC passes of this launch shape, not a measurement of this run"
+            if tr.get('valu_wave_instr_per_launch'):               # what binds: instruction issue ("report fp64 FLOP/s alongside GB/s")
+                wi, fl = tr['valu_wave_instr_per_launch'], tr.get('fp64_flop_per_launch')
+                valu = {'wave_instr_per_launch': wi, 'wave_instr_per_s': wi / (avg_ms * 1e-3), 'peak': VALU_PEAK_WAVE_INSTR_PER_S,
+                        'peak_note': '1024 SIMDs x one wave64 VALU instruction per 4 cycles x 2.4 GHz peak clock (the part runs this kernel at 1.9-2.1 GHz)',
+                        'frac': wi / (avg_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
+                        'fp64_flops': (fl / (avg_ms * 1e-3)) if fl else None, 'fp64_peak_flops': FP64_VECTOR_PEAK_FLOPS,
+                        'fp64_frac': (fl / (avg_ms * 1e-3) / FP64_VECTOR_PEAK_FLOPS) if fl else None,
+                        'source': 'instruction counts per launch from the committed PMC passes (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64), divided by this run\'s kernel time'}
+        side_ok = world == 1 and headline_shape and not args.no_side
         replay = None
-        if world == 1 and args.config == 2 and not args.no_replay and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
+        if world == 1 and args.config == 2 and not args.no_replay and not args.e2e and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
             replay = replay_side_measurement(torch, engine, uvs_amd, fp, bufs['x'], bufs['err'], T, K, M, N)
         others = None
-        if world == 1 and args.config == 2 and not args.no_side and not args.stats_only and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
-            # the reference's other three estimators on the headline workload: same inputs, same streams logged
+        if side_ok and not args.e2e:
+            # the reference's other three estimators on the headline workload: same inputs, same streams logged;
+            # MCKF once more on alpha = 1.0 noise (the reference's first sweep cell), where its fixed-point iteration and its FAIL path are live
             others = {}
-            fp_head = fp
-            for meth in ('KF', 'IMCCKF', 'MCKF'):
+            fp_head, noise_head = fp, noise
+            cfg1 = config2()
+            cfg1['experiments']['epoch'] = trials_total
+            cfg1['noise']['noise_params']['alpha'] = 1.0
+            plan1 = batch.plan_trials(cfg1, cells=[1.0])
+            for key, meth, alpha in (('KF', 'KF', ALPHA), ('IMCCKF', 'IMCCKF', ALPHA), ('MCKF', 'MCKF', ALPHA), ('MCKF_alpha1', 'MCKF', 1.0)):
                 fp = engine.make_params(M, N, meth, fp_head.kernel_bw, bool(fp_head.annealing), fp_head.dt, fp_head.dt * fp_head.k_max, fp_head.gain,
                                         list(fp_head.desired)[:M], bool(fp_head.initial_guess), args.lanes)
+                if alpha != ALPHA:
+                    noise = batch.device_noise(cfg1, plan1, lo, hi, K, dev)
                 ms = []
                 for i in range(2 + 5):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -474,31 +600,47 @@ def main():
                         ms.append(e0.elapsed_time(e1))
                 upd = int(k_done.sum().item())
                 avg = float(np.mean(ms))
-                others[meth] = {'avg_kernel_ms': avg, 'updates_per_s': upd / (avg * 1e-3), 'achieved': upd * b_alg / (avg * 1e-3) / 1e9, 'unit': 'GB/s',
-                                'frac': upd * b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches_timed': 5, 'failed_trials': int((status != 0).sum().item())}
+                others[key] = {'avg_kernel_ms': avg, 'updates_per_s': upd / (avg * 1e-3), 'achieved': upd * b_alg / (avg * 1e-3) / 1e9, 'unit': 'GB/s',
+                               'frac': upd * b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches_timed': 5, 'alpha': alpha, 'updates_per_launch': upd,
+                               'failed_trials': int((status != 0).sum().item())}
+                noise = noise_head
             fp = fp_head
         side = {}
-        if world == 1 and args.config == 2 and not args.no_side and not args.stats_only and T == TRIALS_PER_GPU and args.layout == 'kct' and args.lanes in (0, 2):
+        if side_ok:
             for key in list(bufs):
                 bufs[key] = None                                   # 9.7 GB of config-2 streams: make room for 44 GB (config 3) / 41 GB (config 5)
+            del noise
             torch.cuda.empty_cache()
-            side['config3'] = side_config(3, torch, uvs_amd, engine, batch, dev)
-            side['config5'] = side_config(5, torch, uvs_amd, engine, batch, dev)
+            side['e2e'] = e2e_sweep(torch, uvs_amd, engine, batch, dev)
+            if not args.e2e:
+                side['config3'] = side_config(3, torch, uvs_amd, engine, batch, dev)
+                side['config3_hold'] = side_config(3, torch, uvs_amd, engine, batch, dev, hold=True)
+                side['config5'] = side_config(5, torch, uvs_amd, engine, batch, dev)
+        series = {'strong': f'strong scaling: {trials_total} trials in total, sharded contiguously over {world} rank(s)' +
+                            (" -- north_star's series (a 65 536-trial batch at 1, 2, 4 and 8 MI355X)" if args.config == 2 and trials_total == TRIALS_PER_GPU else '') +
+                            (' -- BASELINE config 4' if args.config == 4 else ''),
+                  'weak': f'weak scaling: {size} trials on every one of {world} rank(s), global trial numbering'}[scaling]
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': {2: 'BASELINE config 2: 4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable noise alpha=1.5, ',
                                     3: f'BASELINE config 3: 4-feature UR10 closed loop, GMCKF(RMCKF) annealed sigma, Gaussian mixture rho=0.1 mean=50 hold={bool(args.hold)}, ',
+                                    4: 'BASELINE config 4: config-2 inputs (4-feature UR10 closed loop, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5), 1 048 576 trials sharded over the ranks + all-gather of [ISE, IAE, ITAE, status], ',
                                     5: 'BASELINE config 5: synthetic 16-feature / 7-DoF (m=32, n=7) linear plant, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5, '}[args.config] +
-                                   f'{T} trials/GPU x {K} updates, ' + ('statistics only (no per-step streams)' if args.stats_only else 'X+err+q logged per step'), 'trials_per_gpu': T, 'updates_per_trial': K,
-                       'lanes_per_filter': args.lanes or (8 if args.config == 5 else engine.supported_lanes(M, N)[0]), 'layout': args.layout, 'failed_trials': int((status != 0).sum().item())},
+                                   f'{trials_total} trials in total ({T} on rank 0) x {K} updates, ' + ('statistics only (no per-step streams)' if args.stats_only else 'X+err+q logged per step'),
+                       'series': series, 'trials_total': trials_total, 'trials_rank0': T, 'trials_per_gpu': T, 'updates_per_trial': K, 'ranks_seen': ranks_seen,
+                       'lanes_per_filter': args.lanes or (8 if args.config == 5 else engine.supported_lanes(M, N)[0]), 'layout': args.layout, 'failed_trials': failed_total},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
-                         'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch},
+                         'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch,
+                         'binds': 'HBM is the roofline BASELINE.json prescribes; the counters say the kernel is bound by VALU issue at one wavefront per SIMD (see `valu`)',
+                         'valu': valu},
+            'multi_gpu': {'kernel_ms_avg_over_ranks': rank_ms, 'gather_ms': gather_avg, 'gather_inside_timed_region': bool(dist_on), 'backend': args.backend if dist_on else None,
+                          'gather_note': 'all_gather of per-trial [ISE, IAE, ITAE, status] rows (32 B/trial); nccl: HIP events on the launch stream, gloo: host clock'},
             'cpu_baseline': cpu,
             'replay': replay,
-            'config3': side.get('config3'), 'config5': side.get('config5'), 'other_estimators': others,
+            'config3': side.get('config3'), 'config3_hold': side.get('config3_hold'), 'config5': side.get('config5'), 'other_estimators': others, 'e2e': side.get('e2e'),
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},

@@ -36,7 +36,8 @@ def test_bench_line_contract():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
                 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in d, key
-    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'strong'
+    assert d['config']['trials_total'] == 4096 and d['config']['ranks_seen'] == 1 and d['multi_gpu']['gather_inside_timed_region'] is False
     assert d['vs_baseline'] is None and d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['unit'] == 'updates/s'
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']

@@ -118,8 +118,11 @@ struct FpiProbe {
     bool unsure = false;                                         // ... or sits so close to the underflow that only the careful pass may decide
     double row_gamma = 0.0, row_a = 0.0, row_nu = 0.0;           // first-pass gain, h.P h and innovation of the row just processed
 };
-// exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.13321910194...; between the two bounds the kernels do not decide themselves
-constexpr double kExpZeroBelow = -745.14, kExpNonzeroAbove = -745.13;
+// exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.1332191019412076...  The argument itself carries a few ulp of rounding
+// (1.6e-13 absolute) that differ between this arithmetic and numpy's, so within 1e-11 of the boundary the tuned kernels do not decide
+// themselves but mark the trial for the second pass.  (Round 2 used a band of +-0.005: at alpha = 1 that marked ~8 of 65 536 trials per
+// sweep, and the eight lone wavefronts of the second pass took three times as long as the whole first pass.)
+constexpr double kExpZeroBelow = -745.1332191019512, kExpNonzeroAbove = -745.1332191019312;
 // A weight that is subnormal but not 0 -- at most 2^-1024, so that its reciprocal overflows -- does not make inv(Cy) raise: it returns inf,
 // the reference's dense product Br @ inv(Cy) @ Br.T (experiment.py:232) turns 0 * inf into NaN, and the gain, the state and the trial are
 // lost (pinv raises in the control law, :312-316: ExperimentStatus.FAIL at this step).  With Cauchy-like noise and the reference's shipped

@@ -111,6 +111,9 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
     if (!launched) return fail(UVS_ERR_SHAPE, "%s", "(m, n, lanes_per_filter) is not instantiated in libuvs_rmckf");
     if (int rc = check_launch("closed_loop_kernel")) return rc;
+#ifdef UVS_NO_CAREFUL                  // diagnostic build: leave the marks of the first pass in `status` (how many trials does the second pass redo?)
+    return UVS_OK;
+#endif
     // second pass: trials in which the control law met a numerically rank-deficient Jacobian (status left at UVS_STATUS_SUSPECT) are
     // re-run with numpy's pinv semantics (experiment.py:312); wavefronts without such a trial exit at once
     if (!(closed_careful_a(fp->m, fp->n, T, s, A) || closed_careful_b(fp->m, fp->n, T, s, A)))
