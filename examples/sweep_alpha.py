@@ -16,12 +16,13 @@ import uvs_amd  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--config', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'config_reference.json'))
+    ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'config.json'))
     ap.add_argument('--epoch', type=int, default=None)
     ap.add_argument('--method', default='GMCKF')
     ap.add_argument('--csv', default=None, help='also write the reference-format results.csv (small sweeps only)')
     args = ap.parse_args()
     cfg = json.load(open(args.config))
+    cfg.pop('_about', None)
     cfg['estimator']['method'] = args.method
     want = ('err', 'q', 'f') if args.csv else ('err',)
     uvs_amd.batch.run_batch(cfg, epoch=1, want=want)            # warm-up: loads the code object, uploads the ziggurat tables

@@ -639,6 +639,61 @@ def test_full_size_config3_properties(uvs):
         assert ref['k_done'] == K and rel_err(err[:, :, t].cpu().numpy(), ref['err']) <= 1e-8
 
 
+def test_full_size_config3_hold_properties(uvs):
+    """BASELINE config 3 with the outlier hold ON (noise.py:103-116: a sample beyond 20 is repeated for 10 steps) at its full size,
+    262 144 trials x 299 steps, noise from the device generator.  Held outliers make the closed loop amplify rounding (1.16x per step,
+    DESIGN.md), so the pointwise closed-loop gate is a 40-step prefix; the strict gate over all 299 steps is the open-loop replay of
+    the kernel's OWN f / dq streams through the block oracle.  Size-independent properties as for hold off."""
+    import torch
+    import bench
+    from oracle import noise_ref, plant_ref, rmckf_block, rmckf_dense
+    T, K = 262144, 299
+    cfg = bench.config2()
+    cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0, 'rho': 0.1}, hold=True, hold_time=0.5)
+    cfg['estimator']['estimator_params']['annealing'] = True
+    cfg['experiments']['epoch'] = T
+    plan = uvs.batch.plan_trials(cfg, cells=[0.1])
+    noise = uvs.batch.device_noise(cfg, plan, 0, T, K, 'cuda')
+    q0 = torch.as_tensor(plan.q_start.copy(), device='cuda')
+    noise[:, :, T - 1] = noise[:, :, 54321]
+    q0[T - 1] = q0[54321]
+    des = cfg['experiments']['desired_f']
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10, True, 0.05, 15, 0.2, des, True, 0)
+    plant = uvs.SyntheticPlant.ur10(des)
+    full = uvs.engine.closed_loop(fp, plant.to_struct(), q0, noise, want=('err',))
+    err = full['err']
+    assert int(full['status'].sum()) == 0 and bool((full['k_done'] == K).all())
+    assert torch.equal(err[:, :, T - 1], err[:, :, 54321]) and torch.equal(full['stats'][T - 1], full['stats'][54321])
+    lo, hi = 200003, 200003 + 5001
+    part = uvs.engine.closed_loop(fp, plant.to_struct(), q0[lo:hi].contiguous(), noise[:, :, lo:hi].contiguous(), want=('err', 'x', 'f', 'dq'))
+    assert torch.equal(part['err'], err[:, :, lo:hi]) and torch.equal(part['stats'], full['stats'][lo:hi])
+    s2 = uvs.engine.stats_reduce(err, uvs.engine.loop_clock(0.05, 15), full['k_done'])
+    assert torch.allclose(s2, full['stats'], rtol=1e-12, atol=0)
+    # the hold really holds: the generator's stream of a sampled trial equals the host restatement of noise.py, with runs of repeated outliers
+    t = 131071
+    ref_noise = noise_ref.NoiseStreamRef(8, noise_ref.GAUSSIAN_MIXTURE, int(plan.seed[t]), True, 10, std=1.0, mean=50.0, rho=0.1).take(K)
+    got = noise[:, :, t].cpu().numpy()
+    assert np.array_equal(got, ref_noise) and int((np.abs(got[1:]) > 20).sum()) > 50 and np.any((got[1:] == got[:-1]) & (np.abs(got[1:]) > 20))
+    discs = plant_ref.place_discs()
+    for t in (7, 131071, 262143 - 1):                                         # closed loop, 40-step prefix
+        robot = plant_ref.PinholeUR10(0.05)
+        robot.start(plan.q_start[t])
+        x0 = rmckf_dense.analytic_initial_guess(robot, robot.features(), 8, 6)
+        ref = rmckf_block.run_closed_loop(lambda qq: plant_ref.project(plant_ref.fkine_all(qq)[5], discs), plan.q_start[t], des, noise[:, :, t].cpu().numpy(), 0.05, 15,
+                                          0.2, x0, kernel_bw=10.0, annealing=True)
+        assert ref['k_done'] == K and rel_err(err[:40, :, t].cpu().numpy(), ref['err'][:40]) <= 1e-8
+    for j in (0, 2500, 5000):                                                 # open loop over all 299 steps, trials lo + j
+        robot = plant_ref.PinholeUR10(0.05)
+        robot.start(plan.q_start[lo + j])
+        f_init = robot.features()
+        x0 = rmckf_dense.analytic_initial_guess(robot, f_init, 8, 6)
+        f_seq = np.vstack([f_init[None], part['f'][:, :, j].cpu().numpy()])
+        dq_prev = np.vstack([np.zeros((1, 6)), part['dq'][:-1, :, j].cpu().numpy()])
+        ref = rmckf_block.run_replay(f_seq, dq_prev, x0, des, 0.2, 'GMCKF', 10.0, True, 300)
+        assert rel_err(part['x'][:, :, j].cpu().numpy(), ref['X']) <= 1e-10
+        assert rel_err(part['dq'][:, :, j].cpu().numpy(), ref['dq_cmd']) <= 1e-8
+
+
 def test_full_size_config5_properties(uvs):
     """BASELINE config 5 at its full size (65 536 trials x 299 steps, (m, n) = (32, 7), per-trial records): partition invariance and
     duplicates bit-exact, fused statistics = statistics kernel, sampled trials against the block oracle."""

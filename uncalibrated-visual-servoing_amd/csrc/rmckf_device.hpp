@@ -397,6 +397,12 @@ struct Rows {
 // the minimum-norm solution, which an unpivoted QR does not give.  Split of work:
 //   * every least-squares solve watches the spread of |R_cc| (all kernels, a handful of integer instructions): a spread of 2^34 or
 //     more -- or an exactly zero column next to non-zero ones -- marks the trial UVS_STATUS_SUSPECT;
+//     KNOWN GAP: that diagonal is not rank-revealing.  A Jacobian whose columns are badly scaled AND nearly parallel can hide a condition
+//     number beyond 1e15 behind an unremarkable diagonal ([[1, 1e20], [0, 1]]); the hot kernels then return the plain least-squares
+//     solution where numpy would truncate.  Watching max |R_ij| as well costs ~60 instructions per step in the headline kernel (4 %);
+//     the estimated Jacobians of this path have columns within a few decades of each other, and the rank-deficient fixtures of the
+//     reference (tests/golden/rankdef_*) are all caught by the diagonal.  Normal-equation solvers (wide kernel, control wavefronts of
+//     the replay) mark at a spread of 2^20 already and are accurate to ~6e-9 in the command up to cond 1e6;
 //   * suspect trials are re-run from their first step by the `careful` instantiation of the generic kernels, launched right behind
 //     the main kernel by the C ABI, whose control law finishes the same QR with a one-sided Jacobi SVD of the n x n factor R
 //     (pinv(J) y = pinv(R) Q^T y, same singular values as J) and applies numpy's cutoff.  The hot kernels stay free of that code.
@@ -585,8 +591,10 @@ UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
     const bool suspect = spread.suspect();
     if constexpr (CAREFUL) {
         // pinv(J) y = pinv(R) (Q^T y)[0:N]: gather the triangular factor and the transformed right-hand side on every lane of the group
-        // (the test is on replicated values, so the lanes of a group agree) and finish with the SVD
-        if (__any(suspect)) {
+        // and finish with the SVD -- on EVERY solve of a careful kernel, not only when the |R_cc| watch fires again: the diagonal of an
+        // unpivoted QR is not rank-revealing (J = [[1, 1e20], [0, 1]] has spread 1 and condition 1e40), so once a trial is in the careful
+        // pass nothing is left to that heuristic.  For a well-conditioned factor the SVD solve equals the back substitution to rounding.
+        {
             double Rm[N][N], cv[N], ss[N];
 #pragma unroll
             for (int c = 0; c < N; ++c) {
@@ -596,11 +604,9 @@ UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
                 cv[c] = group_pick<L>(a[prow][N], sub, owner);
             }
             svd_solve<N>(Rm, cv, ss);
-            if (suspect) {
 #pragma unroll
-                for (int c = 0; c < N; ++c) sol[c] = ss[c];
-                return true;
-            }
+            for (int c = 0; c < N; ++c) sol[c] = ss[c];
+            return suspect;
         }
     }
 #pragma unroll
@@ -658,18 +664,16 @@ UVS_DEV bool lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&
     bool solved = false;
     if constexpr (CAREFUL) {
         // J = [R^T 0] Q^T, so pinv(J) y = Q [pinv(R^T) y; 0]: the m x m factor goes through the SVD with numpy's cutoff
-        if (__any(suspect)) {
+        {                                                          // every solve of a careful kernel (see lstsq_tall)
             double Rt[M][M], ws[M];
 #pragma unroll
             for (int c = 0; c < M; ++c)
 #pragma unroll
                 for (int j = 0; j < M; ++j) Rt[c][j] = (j > c) ? 0.0 : (j == c ? diag[c] : b[j][c]);
             svd_solve<M>(Rt, y, ws);
-            if (suspect) {
 #pragma unroll
-                for (int c = 0; c < M; ++c) w[c] = ws[c];
-                solved = true;
-            }
+            for (int c = 0; c < M; ++c) w[c] = ws[c];
+            solved = true;
         }
     }
     if (!solved) {

@@ -7,7 +7,8 @@ namespace {
 template <int M, int N, int LL, int METHOD>
 void launch_wide(bool xo, dim3 g, hipStream_t s, const uvs::ClosedArgs &A) {
     // per-trial records ([step][trial][component]) and a whole number of wavefronts: X leaves through the LDS transposition as 1 KB stores
-    const bool rec = xo && A.x_out.sc == 1 && A.x_out.st == M * N && A.T % (64 / LL) == 0;
+    // (the record path stores double2: the base must be 16-byte aligned and the step stride even, or the strided variant takes over)
+    const bool rec = xo && A.x_out.sc == 1 && A.x_out.st == M * N && A.T % (64 / LL) == 0 && (uintptr_t)A.x_out.p % 16 == 0 && A.x_out.sk % 2 == 0;
     if (rec) hipLaunchKernelGGL((uvs::closed_loop_wide_kernel<M, N, LL, METHOD, true, true>), g, dim3(64), 0, s, A);
     else if (xo) hipLaunchKernelGGL((uvs::closed_loop_wide_kernel<M, N, LL, METHOD, true, false>), g, dim3(64), 0, s, A);
     else hipLaunchKernelGGL((uvs::closed_loop_wide_kernel<M, N, LL, METHOD, false, false>), g, dim3(64), 0, s, A);
