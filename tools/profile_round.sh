@@ -12,26 +12,24 @@ python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/benc
 echo "bench line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats_bench.err
 echo "kernel trace done"
-for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$pass -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$pass.log 2>&1
-  echo "pmc $pass done"
-done
 i=0
-for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+for pass in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
-            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_sq$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq$i.log 2>&1
-  echo "pmc sq$i done"
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+  echo "pmc pass $i done"
 done
 cd $REPO
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_all_dispatches.csv
-python3 tools/trace_summary.py $OUT/stats --skip closed_loop_tuned_kernel:5 closed_loop_wide_kernel:2 replay_tuned_kernel:1 replay_rows_kernel:1 > $OUT/kernel_trace_summary.csv
-(for tag in FETCH_SIZE WRITE_SIZE sq1 sq2 sq3; do for k in closed_loop_tuned closed_loop_wide replay_tuned replay_rows noise_kernel; do python3 tools/pmc_summary.py $OUT/pmc_$tag $k; done; done) > $OUT/pmc_summary.txt
+# headline kernel: 5 warm-up dispatches, then the 20 timed ones; what follows at the same grid belongs to the side objects (other estimators use other instantiations; the end-to-end sweep re-launches this one)
+python3 tools/trace_summary.py $OUT/stats --skip "closed_loop_tuned_kernel<8, 6, 2, 5, 0, 2, true> grid=131072:5:20" closed_loop_wide_kernel:2 replay_tuned_kernel:1 replay_rows_kernel:1 > $OUT/kernel_trace_summary.csv
+(for n in 1 2 3 4 5 6; do for k in closed_loop_tuned closed_loop_wide replay_tuned replay_rows noise_kernel; do python3 tools/pmc_summary.py $OUT/pmc_$n $k; done; done) > $OUT/pmc_summary.txt
 cat $OUT/kernel_trace_summary.csv
-head -60 $OUT/pmc_summary.txt
-tail -c 2500 $OUT/bench_line.json
-# keep only the summaries in the merged output
+tail -c 1500 $OUT/bench_line.json
 head -2 $(ls $OUT/stats/*/*kernel_trace.csv | head -1) | cut -c1-600
-head -2 $(ls $OUT/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1) | cut -c1-600
-rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3
+head -2 $(ls $OUT/pmc_1/*/*counter_collection.csv | head -1) | cut -c1-600
+# keep only the summaries in the merged output
+rm -rf $OUT/stats $OUT/pmc_1 $OUT/pmc_2 $OUT/pmc_3 $OUT/pmc_4 $OUT/pmc_5 $OUT/pmc_6

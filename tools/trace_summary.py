@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel (and per grid size: the same kernel serves BASELINE configs 2 and 3) duration statistics from a rocprofv3 --kernel-trace CSV, warm-up dispatches excluded.
 
-usage: tools/trace_summary.py <dir with *kernel_trace.csv> [--skip name:count ...]
+usage: tools/trace_summary.py <dir with *kernel_trace.csv> [--skip name:count[:keep] ...]
 For every kernel: calls, mean / median / min / max over ALL dispatches and over the dispatches that remain after dropping the first
-`count` of the kernels named by --skip (substring match) -- bench.py's warm-up launches, which the --stats table averages in."""
+`count` of the kernels named by --skip (substring match) -- bench.py's warm-up launches, which the --stats table averages in -- and,
+with `:keep`, everything after the next `keep` dispatches (the timed launches; later launches of the same kernel belong to side objects)."""
 import collections
 import csv
 import glob
@@ -11,7 +12,7 @@ import statistics
 import sys
 
 d = sys.argv[1]
-skip = dict((a.split(':')[0], int(a.split(':')[1])) for a in sys.argv[3:]) if len(sys.argv) > 2 and sys.argv[2] == '--skip' else {}
+skip = dict((a.split(':')[0], tuple(int(x) for x in a.split(':')[1:])) for a in sys.argv[3:]) if len(sys.argv) > 2 and sys.argv[2] == '--skip' else {}
 rows = collections.defaultdict(list)
 for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -23,7 +24,10 @@ for name, v in sorted(rows.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
         continue
     v.sort()
     dur = [x[1] / 1e6 for x in v]
-    n_skip = max([c for k, c in skip.items() if k in name] + [0])
+    rule = max([c for k, c in skip.items() if k in name] + [(0,)])
+    n_skip = rule[0]
     kept = dur[n_skip:] if len(dur) > n_skip else dur
+    if len(rule) > 1:
+        kept = kept[:rule[1]]
     short = name.replace('void ', '').split('(')[0] + ' ' + name.split(' ')[-1]
     print(f'"{short}",{len(dur)},{statistics.mean(dur):.4f},{len(dur) - len(kept)},{statistics.mean(kept):.4f},{statistics.median(kept):.4f},{min(kept):.4f},{max(kept):.4f}')

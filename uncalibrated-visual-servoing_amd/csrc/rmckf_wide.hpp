@@ -52,9 +52,12 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     __shared__ double lc[M], ldes[M];                              // f0 - J q0, desired_f
     __shared__ double lt[XREC ? TPW * RECP : 1];                   // transposition buffer of the X records
     __shared__ double lacc[3 * R][64], lfp[R][64];                 // lane-private: ISE / IAE / ITAE accumulators, previous noisy features
-    // PV of the lane's R covariance blocks stay in registers, the others live in LDS and pass through registers while their row is
-    // updated: with all four in registers (L = 8) the compiler overflows VGPRs + AGPRs and spills ~60 dwords per lane to scratch
-    constexpr int PV = (L == 8) ? R - 1 : R, PL = R - PV;
+    // KF and IMCC-KF weigh every row of a filter alike, so all their covariance blocks stay identical (RowShare, rmckf_tuned.hpp): a lane keeps
+    // ONE block, its other rows only move their x.  RMCKF: PV of the lane's R blocks stay in registers, the others live in LDS and pass
+    // through registers while their row is updated: with all four in registers (L = 8) the compiler overflows VGPRs + AGPRs and spills
+    // ~60 dwords per lane to scratch.
+    constexpr bool SHARED_P = (METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF);
+    constexpr int PV = SHARED_P ? 1 : ((L == 8) ? R - 1 : R), PL = SHARED_P ? 0 : R - PV;
     __shared__ double lp[PL > 0 ? PL * NP : 1][64];
 
     const unsigned lane = threadIdx.x;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             for (int j = l; j < N; ++j) {
                 const double v = (l == j) ? 1.0 : 0.0;             // P = I (experiment.py:73)
                 if (r < PV) p[r < PV ? r : 0][Sym<N>::at(l, j)] = v;
-                else lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane] = v;
+                else if constexpr (!SHARED_P) lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane] = v;
             }
         lacc[r][lane] = lacc[R + r][lane] = lacc[2 * R + r][lane] = 0.0;
     }
@@ -166,10 +169,20 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         // ---- estimator rows (experiment.py:166-297)
         double chk = 0.0;
         double *pxr = px;
+        RowShare<N> share;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             UVS_WIDE_FENCE();
-            if (r < PV) {
+            if constexpr (SHARED_P) {
+                if (r == 0) {
+                    NoHook none;
+                    FpiProbe unused;
+                    rmckf_row<N, METHOD>(x[0], p[0], dq, zi[0], neg_half_inv_s2, c_shared, fp.reg, kap[0], chk, unused, none, share);
+                } else {
+                    rmckf_row_follow<N>(x[r], share, dq, zi[r], chk);
+                    kap[r] = 1.0;
+                }
+            } else if (r < PV) {
                 rmckf_row<N, METHOD>(x[r], p[r < PV ? r : 0], dq, zi[r], neg_half_inv_s2, c_shared, fp.reg, kap[r], chk);
             } else {
                 double pb[NP];
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) =
-                        (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
+                        SHARED_P ? p[0][Sym<N>::at(l, j)]
+                                 : (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lp[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }
 }
 
