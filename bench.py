@@ -385,6 +385,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side', action='store_true', help='skip the side measurements of the default run (configs 3 / 3-hold / 5, other estimators, end-to-end sweep)')
     ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end sweep side object (counter passes: its 49 launches of the headline kernel on other noise would be averaged in)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
@@ -611,7 +612,8 @@ def main():
                 bufs[key] = None                                   # 9.7 GB of config-2 streams: make room for 44 GB (config 3) / 41 GB (config 5)
             del noise
             torch.cuda.empty_cache()
-            side['e2e'] = e2e_sweep(torch, uvs_amd, engine, batch, dev)
+            if not args.no_e2e:
+                side['e2e'] = e2e_sweep(torch, uvs_amd, engine, batch, dev)
             if not args.e2e:
                 side['config3'] = side_config(3, torch, uvs_amd, engine, batch, dev)
                 side['config3_hold'] = side_config(3, torch, uvs_amd, engine, batch, dev, hold=True)

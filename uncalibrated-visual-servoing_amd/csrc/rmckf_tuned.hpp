@@ -439,8 +439,11 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 // the treatment of row m is selected per lane.
 // Returns true when the |R_cc| spread marks the Jacobian as numerically rank-deficient (rmckf_device.hpp, "numpy.linalg.pinv
 // semantics"): the caller flags the trial and the careful second pass redoes it; the solution computed here is then discarded.
+// nonfinite: some entry of the panel's Jacobian part is NaN or infinite.  A non-finite entry of column j reaches, through the reflector
+// of an earlier column at the latest, every remaining row of column j, so the squared column norm n2 that column j's own step forms is
+// non-finite: the exponent watch sees it for free, and the closed-loop kernel needs no separate finiteness probe of X (24 instructions per step).
 template <int M, int N, int L>
-UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
+UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N], bool &nonfinite) {
     constexpr int R = M / L;
     double rdiag[N];
     Spread spread;
@@ -486,7 +489,16 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         rhs = pair_from_dyn<L>(rhs, owner);
         sol[c] = rhs * rdiag[c];
     }
+    // (a column that vanished exactly -- lo == 0 -- sends NaNs through the remaining columns by itself: that trial is marked for the careful
+    // second pass, which probes X entry by entry, and is not FAILed here)
+    nonfinite = spread.hi >= 0x7ff00000u && spread.lo != 0u;
     return spread.suspect();
+}
+
+template <int M, int N, int L>
+UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
+    bool unused;
+    return lstsq_tall_tuned<M, N, L>(a, sub, sol, unused);
 }
 
 // Plant constants are broadcast from LDS (one ds_read per pair of doubles) instead of sitting in ~90 SGPRs that the register
@@ -1001,13 +1013,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 asm volatile("" ::: "memory");
             }
         }
-        chk = pair_sum<L>(chk);
-        if constexpr (METHOD == UVS_METHOD_MCKF) chk = mckf_poisoned(fpi, chk);
-        if (alive && !(chk == 0.0)) {                            // pinv would raise (experiment.py:313-316)
-            alive = false;
-            status = UVS_STATUS_FAIL;
-            k_done = k;
-        }
         if (!__any(alive)) break;
         if constexpr (METHOD == UVS_METHOD_MCKF && XREG) {       // register-resident variants: first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
@@ -1034,9 +1039,22 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #ifdef UVS_ABLATE_QR
 #pragma unroll
             for (int j = 0; j < N; ++j) sol[j] = pair_sum<L>(panel[j % R][j] * 1e-4 + panel[(j + 1) % R][N] * 1e-3);
+            chk = pair_sum<L>(chk);
+            bool nonfinite = !(chk == 0.0);
+            const bool suspect = false;
 #else
-            flagged |= alive && lstsq_tall_tuned<M, N, L>(panel, sub, sol);
+            // X non-finite: pinv would raise (experiment.py:313-316).  The verdict comes out of the QR's column norms (lstsq_tall_tuned);
+            // the per-entry probe `chk` that the rows accumulate is dead code in this kernel.
+            bool nonfinite;
+            const bool suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite);
 #endif
+            if constexpr (METHOD == UVS_METHOD_MCKF) nonfinite |= fpi.poison && !fpi.skip;      // the reference's NaN state after a subnormal weight
+            if (alive && nonfinite) {
+                alive = false;
+                status = UVS_STATUS_FAIL;
+                k_done = k;
+            }
+            flagged |= alive && suspect;
 #pragma unroll
             for (int j = 0; j < N; ++j) dq[j] = -fp.gain * sol[j];
         }
