@@ -121,9 +121,12 @@ UVS_DEV double standard_normal(Pcg64 &g, const double *zig) {
 }
 
 // One fresh sample of feature `i` (noise.py:120-207).  gens[]: this feature's main generators (component 0, 1, 2), sel: selector.
+// TYPE: the noise type, fixed at compile time (each instantiation carries only the generators and the code of its own type; with the type
+// chosen at run time every lane held 8 generator states = 64 registers and the kernel ran two wavefronts per SIMD).
+template <int TYPE>
 UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const double *zig) {
     const double HALF_PI = 1.5707963267948966, PI = 3.141592653589793;
-    switch (p.type) {
+    switch (TYPE) {
         case UVS_NOISE_WHITE: return 0.0 + p.std * standard_normal(gens[0], zig);
         case UVS_NOISE_UNIFORM: return gens[0].next_double();                              // uniform(): 0 + 1 * u
         case UVS_NOISE_GAUSSIAN_MIXTURE: {
@@ -173,6 +176,7 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
     return (p.alpha == 1.0) ? p.gamma * x + p.shift + p.delta : p.gamma * x + p.delta;
 }
 
+template <int TYPE>
 __global__ __launch_bounds__(64) void noise_kernel(const NoiseArgs A) {
     const uvs_noise_params &p = A.np;
     const int pairs = p.m / 2;
@@ -180,22 +184,25 @@ __global__ __launch_bounds__(64) void noise_kernel(const NoiseArgs A) {
     if (gid >= A.T * pairs) return;
     const int pair = (int)(gid / A.T);                       // trial fastest: a wavefront holds one pair of 64 consecutive trials
     const long long t = gid % A.T;
-    const int comps = (p.type == UVS_NOISE_GAUSSIAN_MIXTURE) ? 2 : (p.type == UVS_NOISE_GAUSSIAN_BIMODAL ? 3 : 1);
-    const bool has_sel = comps > 1;
+    constexpr int comps = (TYPE == UVS_NOISE_GAUSSIAN_MIXTURE) ? 2 : (TYPE == UVS_NOISE_GAUSSIAN_BIMODAL ? 3 : 1);
+    constexpr bool has_sel = comps > 1;
     const int n_gen = comps * p.m + (has_sel ? p.m : 0);
-    Pcg64 g[2][3], sel[2];
+    Pcg64 g[2][comps], sel[2];
+#pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = 2 * pair + h;
-        for (int c = 0; c < 3; ++c) g[h][c].load(A.states + ((t * n_gen) + i + (c < comps ? c : 0) * p.m) * 4);   // generators[i + c*m], noise.py:134-148
-        sel[h].load(A.states + ((t * n_gen) + (has_sel ? comps * p.m + i : i)) * 4);                              // rhoGenerators[i], noise.py:59
+#pragma unroll
+        for (int c = 0; c < comps; ++c) g[h][c].load(A.states + ((t * n_gen) + i + c * p.m) * 4);                 // generators[i + c*m], noise.py:134-148
+        if constexpr (has_sel) sel[h].load(A.states + ((t * n_gen) + comps * p.m + i) * 4);                       // rhoGenerators[i], noise.py:59
+        else sel[h].sh = sel[h].sl = sel[h].ih = sel[h].il = 0;                                                   // unused
     }
     double cur0 = 0.0, cur1 = 0.0;
     int cnt = 0, cnt_max = 0;                                 // noise_hold_cnt / noise_hold_cnt_max of this pair
     for (int k = 0; k < p.steps; ++k) {
         if (cnt >= cnt_max) {                                 // noise.py:83-113
             cnt = 0;
-            cur0 = draw(p, g[0], sel[0], A.zig);
-            cur1 = draw(p, g[1], sel[1], A.zig);
+            cur0 = draw<TYPE>(p, g[0], sel[0], A.zig);
+            cur1 = draw<TYPE>(p, g[1], sel[1], A.zig);
             cnt_max = (fabs(cur0) > 20.0 || fabs(cur1) > 20.0) ? p.hold_cnt : 0;
         } else {
             ++cnt;                                            // noise.py:114-116

@@ -23,7 +23,14 @@ void uvs_launch::debug_math(int which, long long n, const double *x, double *y, 
 void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
     uvs::NoiseArgs A{np, T, states, zig, out};
     const long long lanes = T * (np.m / 2);
-    hipLaunchKernelGGL(uvs::noise_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, A);
+    const dim3 g((unsigned)((lanes + 63) / 64));
+    switch (np.type) {                                             // one instantiation per noise type (noise.py:7-12)
+        case UVS_NOISE_WHITE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_WHITE>, g, dim3(64), 0, s, A); break;
+        case UVS_NOISE_GAUSSIAN_MIXTURE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_MIXTURE>, g, dim3(64), 0, s, A); break;
+        case UVS_NOISE_GAUSSIAN_BIMODAL: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_BIMODAL>, g, dim3(64), 0, s, A); break;
+        case UVS_NOISE_ALPHA_STABLE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A); break;
+        default: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_UNIFORM>, g, dim3(64), 0, s, A); break;
+    }
 }
 
 void uvs_launch::pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s) {
