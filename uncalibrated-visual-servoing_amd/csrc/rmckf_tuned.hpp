@@ -461,12 +461,12 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         spread.add(n2);
         double nrm, rn;
         fast_sqrt_rsqrt_1(n2, nrm, rn);                                 // |R_cc| and its reciprocal
-        const bool zero = !(n2 > 0.0);
-        const bool neg = !(piv >= 0.0);
-        const double alpha = neg ? nrm : -nrm;                          // R_cc = -sign(piv) |column|
-        const double vp = piv - alpha;                                  // = sign(piv) (|piv| + nrm)
+        // R_cc = -sign(piv) |column|; v_pivot = piv - R_cc = sign(piv) (|piv| + nrm): sign transfers (v_bfi), no compares or selects.
+        // A column that vanished (n2 == 0) sends NaNs through the rest of the solve: nothing guards against it here, because such a trial is
+        // marked (spread.lo == 0) and redone by the careful second pass whatever this solve returns.
+        const double vp = piv + copysign(nrm, piv);
         // tau = 2 / (v.v) = 1 / (nrm (nrm + |piv|)) = rn / |vp|
-        const double tau = zero ? 0.0 : rn * fast_rcp_1(fabs(vp));
+        const double tau = rn * fast_rcp_1(fabs(vp));
         const double vm = is_piv ? vp : (is_below ? a[m][c] : 0.0);     // this lane's entry of the Householder vector in row m
 #pragma unroll
         for (int j = c + 1; j <= N; ++j) {
@@ -478,7 +478,7 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
 #pragma unroll
             for (int r = m + 1; r < R; ++r) a[r][j] = fma(-d, a[r][c], a[r][j]);
         }
-        rdiag[c] = zero ? 0.0 : (neg ? rn : -rn);                       // 1 / R_cc straight from the rsqrt
+        rdiag[c] = -copysign(rn, piv);                                  // 1 / R_cc straight from the rsqrt
     }
 #pragma unroll
     for (int c = N - 1; c >= 0; --c) {
