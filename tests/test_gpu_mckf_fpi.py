@@ -189,3 +189,27 @@ def test_monte_carlo_batch_matches_c_oracle_mckf(uvs):
         ok = calm & (ref['status'] == 0)
         sdev = np.abs(out['stats'].cpu().numpy()[ok] - ref['stats'][ok]) / ref['stats'][ok]
         assert sdev.max() <= 1e-8
+
+
+@pytest.mark.parametrize('route', ['device_plant', 'external_robot'])
+@pytest.mark.parametrize('name', ['fpi_mckf_a1p5_thr1em6', 'fpi_default_a1p0_seed0', 'fpi_mckf_a1p2_cap4'])
+def test_experiment_api_drop_in_fpi(uvs, name, route):
+    """Experiment(...).run() with the reference's call signature on runs whose fixed-point iteration iterates, skips or ends in FAIL:
+    the 9-tuple of the reference, logs trimmed to the FAILing step (experiment.py:345-352).  Both routes: whole trial in one kernel, and
+    the Python loop around a robot the package knows nothing about with one estimator step per call (uvs_rmckf_step_f64)."""
+    from oracle.plant_ref import PinholeUR10
+    g = load_golden(name)
+    meta = g['meta']
+    prof = uvs.NoiseProfiler(num_features=8, noise_type=uvs.NoiseType.ALPHA_STABLE, seed=meta['seed'], noise_hold=False, noise_hold_cnt=10,
+                             noise_params=meta['noise_params'])
+    robot = uvs.SyntheticRobot(dt=meta['dt']) if route == 'device_plant' else PinholeUR10(meta['dt'])
+    ex = uvs.Experiment(q_start=g['q_start'], desired_f=g['desired'], noise_prof=prof, t_s=meta['dt'], t_max=meta['t_max'], ibvs_gain=meta['gain'],
+                        robot=robot, method=uvs.Method.MCKF, method_params=meta['params'])
+    status, t, err, q, f, fd, cam, noise, bw = ex.run()
+    k = len(g['t'])
+    assert status.value == int(g['status']) and len(t) == k == len(err) == len(q) == len(f) == len(fd) == len(cam) == len(noise) == len(bw)
+    assert np.array_equal(t, g['t']) and np.array_equal(noise, g['noise'])
+    tol = TOL.get(name, 1e-8)
+    for got, ref in ((err, g['err']), (q, g['q']), (f, g['f'])):
+        assert rel_err(got, ref) <= tol
+    assert np.array_equal(bw, g['sigma_log'])
