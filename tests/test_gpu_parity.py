@@ -725,3 +725,45 @@ def test_full_size_config5_properties(uvs):
     for t in (3, 40001, 65534):
         ref = rmckf_block.run_closed_loop(lin.features, q0_host[t], des, noise[:, t].cpu().numpy(), 0.05, 15, 0.2, x0_row, initial_guess=False)
         assert ref['k_done'] == K and rel_err(err[:, t].cpu().numpy(), ref['err']) <= 1e-8
+
+
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'MCKF'])
+def test_closed_loop_on_a_general_dh_table(uvs, method):
+    """The tuned two-lane kernel picks an instantiation with compile-time zeros for UR10-like DH tables (alpha = -pi/2 on the first and 0 on
+    the last link of either half chain).  A table that is NOT of that pattern -- every alpha tilted by a few hundredths of a radian -- must
+    take the general chain code of the same kernel: 96 trials x 80 steps against oracle/c on the same tilted plant, and against the
+    generic template; and on the UR10 table itself the two chain codes must agree to rounding."""
+    from oracle import c_oracle
+    import bench
+    cfg = bench.config2()
+    desired = np.array(cfg['experiments']['desired_f'])
+    T, K = 96, 80
+    rng = np.random.default_rng(31)
+    q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
+    q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
+    noise = 0.5 * rng.standard_t(3, size=(T, K, 8))
+    tilted = uvs.SyntheticPlant.ur10(desired)
+    tilted.alpha = tilted.alpha + np.array([0.02, -0.03, 0.015, -0.01, 0.025, 0.02])
+    pl = c_oracle.ur10_plant()
+    for i in range(6):
+        pl.alpha[i] = tilted.alpha[i]
+    for i, w in enumerate(tilted.points):
+        for c in range(3):
+            pl.points[i][c] = w[c]
+    ref = c_oracle.closed_loop_batch(q0, noise, desired, method=method, steps=K, want_x=True, plant=pl)
+    outs = {}
+    for lanes in (0, -2):
+        fp = uvs.engine.make_params(8, 6, method, 10.0, False, 0.05, 15.0, 0.2, desired, True, lanes, K)
+        out = uvs.engine.closed_loop(fp, tilted.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q'))
+        assert np.array_equal(out['status'].cpu().numpy(), ref['status']) and np.array_equal(out['k_done'].cpu().numpy(), ref['k_done'])
+        ok = ref['status'] == 0
+        for key, rk in (('err', 'err'), ('q', 'q'), ('x', 'X')):
+            assert rel_err(out[key].cpu().numpy().transpose(2, 0, 1)[ok], ref[rk][ok]) <= 1e-8, (lanes, key)
+        outs[lanes] = out
+    ur10 = uvs.SyntheticPlant.ur10(desired)
+    nearly = uvs.SyntheticPlant.ur10(desired)
+    nearly.alpha = nearly.alpha + np.array([1e-13, 0, 0, 0, 0, 0])           # sin(alpha_0) != -1 in the last bit or cos(alpha_0) > 1e-15: general code
+    fp = uvs.engine.make_params(8, 6, method, 10.0, False, 0.05, 15.0, 0.2, desired, True, 0, K)
+    a = uvs.engine.closed_loop(fp, ur10.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('err', 'q'))
+    b = uvs.engine.closed_loop(fp, nearly.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('err', 'q'))
+    assert rel_err(a['err'].cpu().numpy(), b['err'].cpu().numpy()) <= 1e-9 and rel_err(a['q'].cpu().numpy(), b['q'].cpu().numpy()) <= 1e-9

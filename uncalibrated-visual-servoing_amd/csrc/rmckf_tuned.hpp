@@ -501,6 +501,10 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     return lstsq_tall_tuned<M, N, L>(a, sub, sol, unused);
 }
 
+// Internal plant kind (not part of the ABI): UVS_PLANT_DH_PINHOLE whose DH table has, in either half of a six-link chain, alpha = -pi/2 on
+// the first link and alpha = 0 on the last (the UR10: -pi/2, 0, 0 | -pi/2, pi/2, 0).  The launcher selects it when the table says so.
+constexpr int kPlantDhAxisAligned = 2;
+
 // Plant constants are broadcast from LDS (one ds_read per pair of doubles) instead of sitting in ~90 SGPRs that the register
 // allocator would spill to VGPR lanes and fetch back with v_readlane + s_nop on every use.
 template <int M, int N>
@@ -535,7 +539,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
-    constexpr bool SPLIT = (PLANT == UVS_PLANT_DH_PINHOLE) && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
+    constexpr bool DH = (PLANT == UVS_PLANT_DH_PINHOLE || PLANT == kPlantDhAxisAligned);
+    constexpr bool AXIS = (PLANT == kPlantDhAxisAligned);
+    static_assert(!AXIS || (L == 2 && N == 6), "the axis-aligned chain is written for three links per lane");
+    constexpr bool SPLIT = DH && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
     constexpr int G = SPLIT ? (L == 2 ? 2 : 3) : 1;
     constexpr int JG = N / G;                                      // joints tracked by this lane
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;       // rows per lane, packed block size, trials per wavefront
@@ -588,7 +595,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
 
-    if constexpr (PLANT == UVS_PLANT_DH_PINHOLE) {
+    if constexpr (DH) {
         if (lane < N) {
             lds_c[PC::kJoint + 5 * lane + 0] = A.plant.theta_offset[lane];
             lds_c[PC::kJoint + 5 * lane + 1] = A.plant.d[lane];
@@ -754,6 +761,47 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 reseed = false;
             }
             double T[3][4];                                 // product of this lane's links (the whole chain when !SPLIT)
+            if constexpr (AXIS) {
+                // UR10-like chain (kPlantDhAxisAligned): the first link of either lane group has alpha = -pi/2 and the last alpha = 0, so
+                // cos / sin alpha are 0, -1 resp. 1, 0 at compile time and the products with them are not written down (38 instructions
+                // less per step).  The reference multiplies by cos(-pi/2) = 6.1e-17 instead of 0: a 1e-16 relative difference in the pose.
+                {
+                    const double s = sn[0], c = cs[0], dd = cj[1], aa = cj[2];
+                    T[0][0] = c; T[0][1] = 0.0; T[0][2] = -s; T[0][3] = aa * c;
+                    T[1][0] = s; T[1][1] = 0.0; T[1][2] = c; T[1][3] = aa * s;
+                    T[2][0] = 0.0; T[2][1] = -1.0; T[2][2] = 0.0; T[2][3] = dd;
+                }
+                {                                           // middle link: general alpha, against the known zeros of the first
+                    const double s = sn[1], c = cs[1];
+                    const double dd = cj[5 + 1], aa = cj[5 + 2], ca = cj[5 + 3], sa = cj[5 + 4];
+                    const double l01 = -s * ca, l02 = s * sa, l03 = aa * c;
+                    const double l11 = c * ca, l12 = -c * sa, l13 = aa * s;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {           // T[r][1] == 0
+                        const double t0 = T[r][0], t2 = T[r][2], t3 = T[r][3];
+                        T[r][0] = t0 * c;
+                        T[r][1] = fma(t0, l01, t2 * sa);
+                        T[r][2] = fma(t0, l02, t2 * ca);
+                        T[r][3] = fma(t0, l03, fma(t2, dd, t3));
+                    }
+                    const double t3 = T[2][3];              // row 2 of the first link is (0, -1, 0, d)
+                    T[2][0] = -s;
+                    T[2][1] = -l11;
+                    T[2][2] = -l12;
+                    T[2][3] = t3 - l13;
+                }
+                {                                           // last link: alpha = 0
+                    const double s = sn[2], c = cs[2], dd = cj[10 + 1], aa = cj[10 + 2];
+                    const double l03 = aa * c, l13 = aa * s;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double t0 = T[r][0], t1 = T[r][1], t2 = T[r][2], t3 = T[r][3];
+                        T[r][0] = fma(t0, c, t1 * s);
+                        T[r][1] = fma(t1, c, -(t0 * s));
+                        T[r][3] = fma(t0, l03, fma(t1, l13, fma(t2, dd, t3)));
+                    }
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < JG; ++u) {
                 const double s = sn[u], c = cs[u];
@@ -1097,7 +1145,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             lds_acc[2 * R + r][lane] = fma(t, ae, acc_now[2 * R + r]);
         }
         UVS_STAMP(3);                                            // logs + statistics
-        if constexpr (UVS_INC_SINCOS && PLANT == UVS_PLANT_DH_PINHOLE) {
+        if constexpr (UVS_INC_SINCOS && DH) {
 #pragma unroll
             for (int u = 0; u < JG; ++u) {
                 const double d = dq_own[u] * fp.dt;
