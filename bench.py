@@ -231,7 +231,7 @@ def side_config(config, torch, uvs_amd, engine, batch, dev, trials=None, reps=5,
         fp = engine.make_params(8, 6, 'GMCKF', 10, True, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, lanes)
         plant, x0 = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct(), None
         workload = f'BASELINE config 3: 4-feature UR10 closed loop, GMCKF(RMCKF) annealed sigma, Gaussian mixture rho=0.1 mean=50 hold={bool(hold)}, {T} trials x {K} updates, X+err+q logged'
-        kernel = 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>'
+        kernel = 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned UR10 table),2,true>'
     else:
         T, M, N, layout = trials or TRIALS_PER_GPU, 32, 7, 'ktc'
         cfg['experiments']['epoch'] = T
@@ -634,7 +634,7 @@ def main():
                        'series': series, 'trials_total': trials_total, 'trials_rank0': T, 'trials_per_gpu': T, 'updates_per_trial': K, 'ranks_seen': ranks_seen,
                        'lanes_per_filter': args.lanes or (8 if args.config == 5 else engine.supported_lanes(M, N)[0]), 'layout': args.layout, 'failed_trials': failed_total},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH,2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
+                         'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned UR10 table),2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch,
                          'binds': 'HBM is the roofline BASELINE.json prescribes; the counters say the kernel is bound by VALU issue at one wavefront per SIMD (see `valu`)',
                          'valu': valu},
