@@ -268,7 +268,7 @@ def test_default_kernels_have_no_scratch():
     k = kernel_resources.kernels()
     assert len(k) > 100
     for method in (2, 3, 4, 5):                                              # KF, MCKF, IMCCKF, GMCKF
-        for plant in (0, 1):
+        for plant in (0, 1, 2):                                              # DH, linear, DH with the UR10-like table's compile-time zeros
             for xout in ('true', 'false'):
                 r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}>']
                 assert r['scratch'] == 0 and r['vgpr'] <= 512, (method, plant, xout, r)
