@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Long randomised cross-check of the closed-loop kernels against oracle/c (not part of the test suite: minutes of GPU and CPU time).
+Every case draws estimator, lane variant, batch size, horizon, step, gain, bandwidth, annealing, noise law and scale, MCKF threshold and
+cap; trials the oracle itself does not reproduce from starts moved by 1e-14 (chaotic closed loops) are held to nothing, everybody else to
+status / k_done exactly and trajectories <= 1e-8.   usage (GPU box): python tools/fuzz_long.py [cases] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import uvs_amd as uvs  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+import bench  # noqa: E402
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
+    cfg = bench.config2()
+    desired = cfg['experiments']['desired_f']
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    lanes_of = {'GMCKF': [0, 2, 4, 1, -2], 'KF': [0, 2, 4, -4], 'IMCCKF': [0, 2, 4, -2], 'MCKF': [0, 2, 4, -2, 1, -4]}
+    worst, bad, n_calm, n_all, n_fail, n_multi = 0.0, [], 0, 0, 0, 0
+    t0 = time.time()
+    for case in range(cases):
+        method = ['GMCKF', 'KF', 'IMCCKF', 'MCKF'][case % 4]
+        lane = int(rng.choice(lanes_of[method]))
+        T = int(rng.integers(1, 200))
+        K = int(rng.integers(1, 120))
+        dt = float(rng.choice([0.02, 0.05, 0.1]))
+        t_max = dt * (K + 1) + (dt / 2 if rng.random() < 0.5 else 5.0)
+        gain = float(rng.uniform(0.05, 0.6))
+        bw = float(rng.choice([1.0, 2.0, 10.0, 50.0]))
+        anneal = bool(rng.random() < 0.4)
+        law = rng.choice(['t2.5', 't1.2', 'cauchy', 'normal', 'none'])
+        scale = float(rng.choice([0.5, 3.0, 10.0]))
+        noise = {'t2.5': lambda: rng.standard_t(2.5, size=(T, K, 8)), 't1.2': lambda: rng.standard_t(1.2, size=(T, K, 8)),
+                 'cauchy': lambda: rng.standard_cauchy(size=(T, K, 8)), 'normal': lambda: rng.standard_normal((T, K, 8)),
+                 'none': lambda: np.zeros((T, K, 8))}[law]() * scale
+        thr, cap = float(rng.choice([0.1, 1e-2, 1e-4])), int(rng.choice([1, 2, 5, 1000]))
+        q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
+        q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
+        kw = dict(method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True, fpi_threshold=thr, fpi_epoch_max=cap)
+        ref = c_oracle.closed_loop_batch(q0, noise, desired, **kw)
+        ref2 = c_oracle.closed_loop_batch(q0 * (1.0 + 1e-14), noise, desired, **kw)
+        fp = uvs.engine.make_params(8, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K, thr, cap)
+        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0)), device='cuda'),
+                                     want=('x', 'err', 'q'))
+        st, kd = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
+        X, E, Q = (out[k].cpu().numpy().transpose(2, 0, 1) for k in ('x', 'err', 'q'))
+        tag = (case, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
+        n_fail += int((ref['status'] == 1).sum())
+        if method == 'MCKF':
+            n_multi += int((ref['fpi'] >= 2).sum())
+        for t in range(T):
+            n_all += 1
+            k1, k2 = int(ref['k_done'][t]), int(ref2['k_done'][t])
+            calm = ref['status'][t] == ref2['status'][t] and k1 == k2 and (k1 == 0 or max(rel(ref2[r][t, :k1], ref[r][t, :k1]) for r in ('err', 'q', 'X')) <= 1e-11)
+            if not calm:
+                continue
+            n_calm += 1
+            if st[t] != ref['status'][t] or kd[t] != k1:
+                bad.append(('status', tag, t, int(st[t]), int(kd[t]), int(ref['status'][t]), k1))
+                continue
+            if k1:
+                d = max(rel(E[t, :k1], ref['err'][t, :k1]), rel(Q[t, :k1], ref['q'][t, :k1]), rel(X[t, :k1], ref['X'][t, :k1]))
+                worst = max(worst, d)
+                if d > 1e-8:
+                    bad.append(('deviation', tag, t, d))
+        if case % 25 == 24:
+            print(f'{case + 1} cases, {n_all} trials ({n_calm} calm, {n_fail} FAIL in the oracle, {n_multi} multi-pass MCKF steps), worst calm deviation {worst:.2e}, '
+                  f'{len(bad)} mismatches, {time.time() - t0:.0f} s', flush=True)
+    for b in bad[:40]:
+        print('MISMATCH', b)
+    print('done:', cases, 'cases,', n_all, 'trials,', n_calm, 'calm,', len(bad), 'mismatches, worst', f'{worst:.3e}')
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
