@@ -81,3 +81,62 @@ def test_gpu_sweep_writes_the_reference_file(name, tmp_path):
                       (['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw'], 1e-8)):
         a, b = got[cols].values, df[cols].values
         assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), cols
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_parquet_sink_holds_the_reference_table(name, tmp_path):
+    """batch.write_results_parquet: the same 41 columns as the reference's results.csv, streamed in row groups.  Fed with the fixture's own
+    streams it must return the fixture's table: pass-through columns exactly, camera pose from our kinematics, status strings, row order; a
+    trial cut short (k_done < K, as after a FAIL) loses its trailing rows like the reference's trimmed logs."""
+    import torch
+    import uvs_amd
+    text, df, cfg = _load(name)
+    plan = uvs_amd.batch.plan_trials(cfg)
+    T, K = len(plan), 10
+    stream = lambda prefix, n: torch.as_tensor(np.stack([df[df.experiment_id == j][[f'{prefix}_{i}' for i in range(1, n + 1)]].values for j in range(T)], axis=2))  # noqa: E731
+    k_done = torch.full((T,), K, dtype=torch.int32)
+    status = torch.zeros(T, dtype=torch.int32)
+    k_done[5], status[5] = 4, 1                                               # pretend trial 5 FAILed at step 4
+    res = SimpleNamespace(plan=plan, lo=0, hi=T, t=uvs_amd.engine.loop_clock(0.05, cfg['experiments']['t_max']), status=status, k_done=k_done,
+                          streams={'q': stream('q', 6), 'f': stream('f', 8)}, noise=stream('noise', 8))
+    path = tmp_path / 'results.parquet'
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f'])
+    rows = uvs_amd.batch.write_results_parquet(res, cfg, plant, str(path), trials_per_group=5)       # three row groups
+    got = pd.read_parquet(path)
+    want = df[~((df.experiment_id == 5) & (df.groupby('experiment_id').cumcount() >= 4))].reset_index(drop=True)
+    assert rows == len(got) == len(want) == T * K - 6 and list(got.columns) == uvs_amd.batch.CSV_COLUMNS
+    exact = ['experiment_id', 'rho', 't'] + [f'q_{i}' for i in range(1, 7)] + [f'f_{i}' for i in range(1, 9)] + [f'desired_f_{i}' for i in range(1, 9)] + \
+            [f'noise_{i}' for i in range(1, 9)] + ['kernel_bw']
+    for col in exact:
+        assert np.array_equal(got[col].values, want[col].values), col
+    cam = ['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw']
+    assert np.allclose(got[cam].values, want[cam].values, rtol=0, atol=1e-12)
+    st = got['status'].astype(str).values
+    assert set(st[got.experiment_id.values != 5]) == {'ExperimentStatus.SUCCESS'} and set(st[got.experiment_id.values == 5]) == {'ExperimentStatus.FAIL'}
+    import pyarrow.parquet as pq
+    assert pq.ParquetFile(path).num_row_groups == 3
+    # the batched pose equals the scalar one
+    q = np.random.default_rng(0).uniform(-2, 2, (7, 3, 6))
+    one = np.array([[uvs_amd.plant.camera_pose(plant.fkine_all(q[i, j])[-1]) for j in range(3)] for i in range(7)])
+    assert np.allclose(plant.camera_pose_batch(q), one, rtol=0, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_gpu_sweep_parquet_equals_csv(tmp_path):
+    """A 12-cell MCKF sweep at alpha-stable noise (some trials FAIL): the Parquet sink and the reference-format CSV sink hold the same table."""
+    import uvs_amd
+    _, _, cfg = _load('results_mckf_anneal')
+    cfg['experiments'].update(epoch=40, t_max=15)
+    res = uvs_amd.batch.run_batch(cfg, want=('err', 'q', 'f'))
+    assert int((res.status != 0).sum()) > 0
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f'])
+    uvs_amd.batch.write_results_csv(res, cfg, plant, str(tmp_path / 'r.csv'))
+    rows = uvs_amd.batch.write_results_parquet(res, cfg, plant, str(tmp_path / 'r.parquet'), trials_per_group=100)
+    a = pd.read_csv(tmp_path / 'r.csv', float_precision='round_trip')
+    b = pd.read_parquet(tmp_path / 'r.parquet')
+    assert rows == len(a) == len(b) == int(res.k_done.sum()) and list(a.columns) == list(b.columns)
+    for col in a.columns:
+        if col == 'status':
+            assert list(a[col].astype(str)) == list(b[col].astype(str))
+        else:
+            assert np.allclose(a[col].values, b[col].values, rtol=1e-15, atol=1e-12), col

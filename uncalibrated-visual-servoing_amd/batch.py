@@ -14,7 +14,7 @@ import numpy as np
 from . import dist, engine, noise_device
 from .experiment import ExperimentStatus, Method, bandwidth_log
 from .noise import NoiseProfiler, NoiseType, noise_batch
-from .plant import SyntheticPlant, camera_pose
+from .plant import SyntheticPlant
 
 REQUIRED = {'experiments': ('dt', 't_max', 'epoch', 'ibvs_gain', 'q_start', 'desired_f', 'visualization', 'change_q_start', 'seed'),
             'estimator': ('method', 'estimator_params'),
@@ -183,9 +183,7 @@ def write_results_csv(result, cfg, plant, path):
     header = not os.path.exists(path)
     for j in range(result.hi - result.lo):
         k = int(k_done[j])
-        cam = np.zeros((k, 6))
-        for i in range(k):
-            cam[i] = camera_pose(plant.fkine_all(q[i, :, j])[-1])   # computePose (ur10_simulation.py:151-163)
+        cam = plant.camera_pose_batch(q[:k, :, j]) if k else np.zeros((0, 6))   # computePose (ur10_simulation.py:151-163)
         cols = {'experiment_id': result.lo + j, 'status': ExperimentStatus(int(status[j])), 'rho': result.plan.value[result.lo + j],
                 't': result.t[:k]}
         cols.update({f'q_{i + 1}': q[:k, i, j] for i in range(6)})
@@ -197,6 +195,51 @@ def write_results_csv(result, cfg, plant, path):
                                           cfg['experiments']['t_max'])                      # -1 unless MCKF (experiment.py:330)
         pd.DataFrame(data=cols).to_csv(path, mode='a', index=False, header=header)
         header = False
+
+
+def write_results_parquet(result, cfg, plant, path, trials_per_group=2048):
+    """The reference's results table (main.py:152-196: one row per logged step, the 41 columns of results.csv, same names, same order) as a
+    Parquet file, for sweeps where the long-format CSV is impractical (65 536 trials x 299 rows x 41 columns is 6.7 GB of text).  Streams:
+    ``trials_per_group`` trials at a time are copied from the device, expanded and written as one row group, so the host never holds more
+    than one group (2 048 trials = 612 352 rows = 200 MB).  ``status`` is the reference's string (``ExperimentStatus.SUCCESS``), dictionary
+    encoded; rows at and after a FAILed trial's k_done are dropped as the reference trims them (experiment.py:345-352).  Needs the 'q' and
+    'f' streams.  Returns the number of rows written."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    desired = np.asarray(cfg['experiments']['desired_f'], float)
+    method, p = Method[cfg['estimator']['method']], cfg['estimator']['estimator_params']
+    status_all, k_all = result.status.cpu().numpy(), result.k_done.cpu().numpy()
+    T, K = result.hi - result.lo, len(result.t)
+    bw_full = bandwidth_log(method, K, p.get('kernel_bw', 1.0), p.get('annealing', False), cfg['experiments']['dt'], cfg['experiments']['t_max'])
+    names = {0: str(ExperimentStatus(0)), 1: str(ExperimentStatus(1))}
+    writer, rows_written = None, 0
+    try:
+        for a in range(0, T, trials_per_group):
+            b = min(T, a + trials_per_group)
+            q = result.streams['q'][:, :, a:b].cpu().numpy()               # [K][6][chunk]
+            f = result.streams['f'][:, :, a:b].cpu().numpy()
+            nz = result.noise[:, :, a:b].cpu().numpy()
+            keep = (np.arange(K)[None, :] < k_all[a:b, None])              # (chunk, K): logged rows
+            tt, kk = np.nonzero(keep)                                      # trial-major, step-minor: the reference's row order
+            cam = plant.camera_pose_batch(np.moveaxis(q, 1, 2)[kk, tt])     # (rows, 6)
+            cols = {'experiment_id': (result.lo + a + tt).astype(np.int64),
+                    'status': pa.array([names[int(v)] for v in status_all[a:b]]).dictionary_encode().take(pa.array(tt)),
+                    'rho': result.plan.value[result.lo + a + tt], 't': np.asarray(result.t)[kk]}
+            cols.update({f'q_{i + 1}': q[kk, i, tt] for i in range(6)})
+            cols.update({name: cam[:, i] for i, name in enumerate(CSV_COLUMNS[10:16])})
+            cols.update({f'f_{i + 1}': f[kk, i, tt] for i in range(8)})
+            cols.update({f'desired_f_{i + 1}': np.full(len(tt), desired[i]) for i in range(8)})
+            cols.update({f'noise_{i + 1}': nz[kk, i, tt] for i in range(8)})
+            cols['kernel_bw'] = bw_full[kk]
+            table = pa.table({name: cols[name] for name in CSV_COLUMNS})
+            if writer is None:
+                writer = pq.ParquetWriter(path, table.schema, compression='zstd')
+            writer.write_table(table)
+            rows_written += len(tt)
+    finally:
+        if writer is not None:
+            writer.close()
+    return rows_written
 
 
 def save_results_npz(result, cfg, path, streams=True):

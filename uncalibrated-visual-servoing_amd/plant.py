@@ -98,6 +98,29 @@ class SyntheticPlant:
             z, p = T[:3, 2], T[:3, 3]
         return np.stack(cols, axis=1)
 
+    def camera_pose_batch(self, q):
+        """camera_pose(fkine(q)) for a whole array of joint vectors, q of shape (..., n) -> (..., 6): the same link products as
+        ``link`` / ``fkine_all`` (ur10_simulation.py:97-110, 204-211) evaluated with stacked 4 x 4 matrices, for the sinks that log the
+        camera pose of every step of every trial (results.csv / Parquet, main.py:160-165)."""
+        q = np.asarray(q, float)
+        T = None
+        for i in range(self.n_joints):
+            th = q[..., i] + self.theta_offset[i]
+            c, s = np.cos(th), np.sin(th)
+            ca, sa = np.cos(self.alpha[i]), np.sin(self.alpha[i])
+            A = np.zeros(q.shape[:-1] + (4, 4))
+            A[..., 0, 0], A[..., 0, 1], A[..., 0, 2], A[..., 0, 3] = c, -s * ca, s * sa, self.a[i] * c
+            A[..., 1, 0], A[..., 1, 1], A[..., 1, 2], A[..., 1, 3] = s, c * ca, -c * sa, self.a[i] * s
+            A[..., 2, 1], A[..., 2, 2], A[..., 2, 3] = sa, ca, self.d[i]
+            A[..., 3, 3] = 1.0
+            T = A if T is None else T @ A
+        pose = np.empty(q.shape[:-1] + (6,))
+        pose[..., :3] = T[..., :3, 3]
+        pose[..., 3] = np.arctan2(T[..., 2, 1], T[..., 2, 2])
+        pose[..., 4] = np.arcsin(np.clip(-T[..., 2, 0], -1.0, 1.0))
+        pose[..., 5] = np.arctan2(T[..., 1, 0], T[..., 0, 0])
+        return pose
+
     def project(self, T):
         R, t = T[:3, :3], T[:3, 3]
         f = np.empty(2 * self.n_points)
