@@ -26,13 +26,24 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
     cfg = bench.config2()
     desired = cfg['experiments']['desired_f']
-    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
     lanes_of = {'GMCKF': [0, 2, 4, 1, -2], 'KF': [0, 2, 4, -4], 'IMCCKF': [0, 2, 4, -2], 'MCKF': [0, 2, 4, -2, 1, -4]}
+    shapes = {}
+    for m in (8, 6, 2):                                            # 4, 3 and 1 features (BASELINE configs 2 and 1; the reference's tests/*_3_features)
+        des = desired[:m]
+        host = uvs.SyntheticPlant.ur10(des)
+        pl = c_oracle.ur10_plant()
+        pl.n_points = m // 2
+        for i, w in enumerate(host.points):
+            for c in range(3):
+                pl.points[i][c] = w[c]
+        shapes[m] = (des, host.to_struct(), pl)
     worst, bad, n_calm, n_all, n_fail, n_multi = 0.0, [], 0, 0, 0, 0
     t0 = time.time()
     for case in range(cases):
         method = ['GMCKF', 'KF', 'IMCCKF', 'MCKF'][case % 4]
-        lane = int(rng.choice(lanes_of[method]))
+        m = int(rng.choice([8, 8, 8, 6, 2]))
+        desired, plant, pl = shapes[m]
+        lane = int(rng.choice(lanes_of[method])) if m == 8 else int(rng.choice({6: [0, 2, 1], 2: [0, 1]}[m]))
         T = int(rng.integers(1, 200))
         K = int(rng.integers(1, 120))
         dt = float(rng.choice([0.02, 0.05, 0.1]))
@@ -42,21 +53,21 @@ def main():
         anneal = bool(rng.random() < 0.4)
         law = rng.choice(['t2.5', 't1.2', 'cauchy', 'normal', 'none'])
         scale = float(rng.choice([0.5, 3.0, 10.0]))
-        noise = {'t2.5': lambda: rng.standard_t(2.5, size=(T, K, 8)), 't1.2': lambda: rng.standard_t(1.2, size=(T, K, 8)),
-                 'cauchy': lambda: rng.standard_cauchy(size=(T, K, 8)), 'normal': lambda: rng.standard_normal((T, K, 8)),
-                 'none': lambda: np.zeros((T, K, 8))}[law]() * scale
+        noise = {'t2.5': lambda: rng.standard_t(2.5, size=(T, K, m)), 't1.2': lambda: rng.standard_t(1.2, size=(T, K, m)),
+                 'cauchy': lambda: rng.standard_cauchy(size=(T, K, m)), 'normal': lambda: rng.standard_normal((T, K, m)),
+                 'none': lambda: np.zeros((T, K, m))}[law]() * scale
         thr, cap = float(rng.choice([0.1, 1e-2, 1e-4])), int(rng.choice([1, 2, 5, 1000]))
         q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
         q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
-        kw = dict(method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True, fpi_threshold=thr, fpi_epoch_max=cap)
+        kw = dict(method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True, fpi_threshold=thr, fpi_epoch_max=cap, plant=pl)
         ref = c_oracle.closed_loop_batch(q0, noise, desired, **kw)
         ref2 = c_oracle.closed_loop_batch(q0 * (1.0 + 1e-14), noise, desired, **kw)
-        fp = uvs.engine.make_params(8, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K, thr, cap)
+        fp = uvs.engine.make_params(m, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K, thr, cap)
         out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0)), device='cuda'),
                                      want=('x', 'err', 'q'))
         st, kd = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
         X, E, Q = (out[k].cpu().numpy().transpose(2, 0, 1) for k in ('x', 'err', 'q'))
-        tag = (case, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
+        tag = (case, m, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
         n_fail += int((ref['status'] == 1).sum())
         if method == 'MCKF':
             n_multi += int((ref['fpi'] >= 2).sum())
