@@ -268,6 +268,64 @@ static int mckf_step(int m, int n, double *X, double P[][MAXN * MAXN], const dou
     return it;
 }
 
+/* One predict + correct of the estimator (experiment.py:166-297) on the row form: f, f_old the noisy features of this and the previous step,
+ * h the regressor (the previous command; zeros on the first step), k the step index (annealing).  Updates X and the blocks P in place, fills
+ * kappa (the control law's weights, 1 unless GMCKF) and returns the MCKF pass count (0 for the other estimators). */
+static int estimator_step(const oracle_params *fp, int k, double *X, double P[][MAXN * MAXN], const double *f, const double *f_old, const double *h,
+                          double *kappa) {
+    const int m = fp->m, n = fp->n;
+    const double sigma = fp->annealing ? fp->kernel_bw + fp->anneal_span * (1.0 - (double)k / fp->k_max) : fp->kernel_bw;
+    double nu[MAXM], cs = 1;
+    for (int i = 0; i < m; ++i) {
+        double pred = 0;
+        for (int j = 0; j < n; ++j) pred += X[i * n + j] * h[j];
+        nu[i] = (f[i] - f_old[i]) - pred;
+    }
+    if (fp->method == 4) {
+        double ss = 0;
+        for (int i = 0; i < m; ++i) ss += nu[i] * nu[i];
+        cs = gaussian_kernel(sqrt(ss), sigma);
+    }
+    if (fp->method == 3) {                                       /* MCKF */
+        double Z[MAXM];
+        for (int i = 0; i < m; ++i) {
+            Z[i] = f[i] - f_old[i];
+            kappa[i] = 1;
+            for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
+        }
+        return mckf_step(m, n, X, P, Z, h, sigma, fp->fpi_threshold, fp->fpi_epoch_max);
+    }
+    for (int i = 0; i < m; ++i) {
+        double g[MAXN], kk[MAXN], a = 0;
+        for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
+        for (int l = 0; l < n; ++l) {
+            g[l] = 0;
+            for (int j = 0; j < n; ++j) g[l] += P[i][l * n + j] * h[j];
+        }
+        for (int l = 0; l < n; ++l) a += h[l] * g[l];
+        double scale = 1, r = 1;
+        kappa[i] = 1;
+        if (fp->method == 5) { kappa[i] = gaussian_kernel(nu[i], sigma); r = 1.0 / (kappa[i] + fp->reg); }
+        if (fp->method == 4) scale = cs;
+        const double s = scale * a + r;
+        for (int l = 0; l < n; ++l) { kk[l] = scale * g[l] / s; X[i * n + l] += kk[l] * nu[i]; }
+        /* Joseph: (I - k h^T) P (I - k h^T)^T + k k^T */
+        double AP[MAXN * MAXN], hp[MAXN];
+        for (int j = 0; j < n; ++j) {
+            hp[j] = 0;
+            for (int l = 0; l < n; ++l) hp[j] += h[l] * P[i][l * n + j];
+        }
+        for (int l = 0; l < n; ++l)
+            for (int j = 0; j < n; ++j) AP[l * n + j] = P[i][l * n + j] - kk[l] * hp[j];
+        for (int l = 0; l < n; ++l) {
+            double aph = 0;
+            for (int j = 0; j < n; ++j) aph += AP[l * n + j] * h[j];
+            for (int j = 0; j < n; ++j) P[i][l * n + j] = AP[l * n + j] - aph * kk[j] + kk[l] * kk[j];
+        }
+    }
+    return 0;
+}
+
 /* One trial.  noise: [K][m] or NULL; x0: [m*n] when !initial_guess.  Outputs (any may be NULL): err [K][m], q_log [K][n],
  * x_log [K][m*n], stats [3], fpi_log [K] (MCKF passes per step).  Returns status (0 success, 1 fail); *k_done receives the number of logged rows. */
 int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, const double *q_start, const double *noise, const double *x0,
@@ -294,57 +352,10 @@ int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, cons
         features(pl, T[n - 1], f);
         if (noise)
             for (int i = 0; i < m; ++i) f[i] += noise[k * m + i];
-        const double sigma = fp->annealing ? fp->kernel_bw + fp->anneal_span * (1.0 - (double)k / fp->k_max) : fp->kernel_bw;
-        double nu[MAXM], kappa[MAXM], err[MAXM], cs = 1;
-        for (int i = 0; i < m; ++i) {
-            double pred = 0;
-            for (int j = 0; j < n; ++j) pred += X[i * n + j] * dq[j];
-            nu[i] = (f[i] - f_old[i]) - pred;
-            err[i] = f[i] - fp->desired[i];
-        }
-        if (fp->method == 4) {
-            double ss = 0;
-            for (int i = 0; i < m; ++i) ss += nu[i] * nu[i];
-            cs = gaussian_kernel(sqrt(ss), sigma);
-        }
-        if (fp->method == 3) {                                   /* MCKF */
-            double Z[MAXM];
-            for (int i = 0; i < m; ++i) {
-                Z[i] = f[i] - f_old[i];
-                kappa[i] = 1;
-                for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
-            }
-            const int it = mckf_step(m, n, X, P, Z, dq, sigma, fp->fpi_threshold, fp->fpi_epoch_max);
-            if (fpi_log) fpi_log[k] = it;
-        }
-        for (int i = 0; i < m && fp->method != 3; ++i) {
-            double g[MAXN], kk[MAXN], a = 0;
-            for (int j = 0; j < n; ++j) P[i][j * n + j] += 1;
-            for (int l = 0; l < n; ++l) {
-                g[l] = 0;
-                for (int j = 0; j < n; ++j) g[l] += P[i][l * n + j] * dq[j];
-            }
-            for (int l = 0; l < n; ++l) a += dq[l] * g[l];
-            double scale = 1, r = 1;
-            kappa[i] = 1;
-            if (fp->method == 5) { kappa[i] = gaussian_kernel(nu[i], sigma); r = 1.0 / (kappa[i] + fp->reg); }
-            if (fp->method == 4) scale = cs;
-            const double s = scale * a + r;
-            for (int l = 0; l < n; ++l) { kk[l] = scale * g[l] / s; X[i * n + l] += kk[l] * nu[i]; }
-            /* Joseph: (I - k h^T) P (I - k h^T)^T + k k^T */
-            double AP[MAXN * MAXN], hp[MAXN];
-            for (int j = 0; j < n; ++j) {
-                hp[j] = 0;
-                for (int l = 0; l < n; ++l) hp[j] += dq[l] * P[i][l * n + j];
-            }
-            for (int l = 0; l < n; ++l)
-                for (int j = 0; j < n; ++j) AP[l * n + j] = P[i][l * n + j] - kk[l] * hp[j];
-            for (int l = 0; l < n; ++l) {
-                double aph = 0;
-                for (int j = 0; j < n; ++j) aph += AP[l * n + j] * dq[j];
-                for (int j = 0; j < n; ++j) P[i][l * n + j] = AP[l * n + j] - aph * kk[j] + kk[l] * kk[j];
-            }
-        }
+        double kappa[MAXM], err[MAXM];
+        for (int i = 0; i < m; ++i) err[i] = f[i] - fp->desired[i];
+        const int it = estimator_step(fp, k, X, P, f, f_old, dq, kappa);
+        if (fpi_log && fp->method == 3) fpi_log[k] = it;
         double y[MAXM], sol[MAXN];
         for (int i = 0; i < m; ++i) y[i] = kappa[i] * err[i];
         if (pinv_apply(X, m, n, y, sol) != 0) { status = 1; break; }
@@ -365,6 +376,44 @@ int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, cons
     }
     *k_done = k;
     return status;
+}
+
+/* Open-loop replay of recorded streams (what the reference's loop computes when f and the regressor are given, experiment.py:166-312):
+ * f_seq [K+1][m] (row 0 = f_old of the first step), dq_seq [K][n] (row 0 ignored: H = 0 on the first iteration, experiment.py:183), x0 [m*n].
+ * Outputs: x_log [K][m*n], cmd_log [K][n] (the command the control law would issue), kappa_log [K][m], fpi_log [K]; any may be NULL.
+ * Returns status; *k_done = steps completed before X turned non-finite. */
+int uvs_oracle_replay(const oracle_params *fp, const double *f_seq, const double *dq_seq, const double *x0, double *x_log, double *cmd_log,
+                      double *kappa_log, int32_t *k_done, int32_t *fpi_log) {
+    const int m = fp->m, n = fp->n, K = fp->steps;
+    double X[MAXM * MAXN], P[MAXM][MAXN * MAXN], zero[MAXN] = {0};
+    for (int i = 0; i < m * n; ++i) X[i] = x0[i];
+    for (int i = 0; i < m; ++i) {
+        for (int e = 0; e < n * n; ++e) P[i][e] = 0;
+        for (int j = 0; j < n; ++j) P[i][j * n + j] = 1;
+    }
+    int status = 0, k = 0;
+    for (; k < K; ++k) {
+        const double *f = f_seq + (size_t)(k + 1) * m, *f_old = f_seq + (size_t)k * m;
+        double kappa[MAXM], y[MAXM], sol[MAXN];
+        const int it = estimator_step(fp, k, X, P, f, f_old, k == 0 ? zero : dq_seq + (size_t)k * n, kappa);
+        if (fpi_log && fp->method == 3) fpi_log[k] = it;
+        for (int i = 0; i < m; ++i) y[i] = kappa[i] * (f[i] - fp->desired[i]);
+        if (pinv_apply(X, m, n, y, sol) != 0) { status = 1; break; }
+        if (x_log) memcpy(x_log + (size_t)k * m * n, X, sizeof(double) * m * n);
+        if (kappa_log) memcpy(kappa_log + (size_t)k * m, kappa, sizeof(double) * m);
+        if (cmd_log)
+            for (int j = 0; j < n; ++j) cmd_log[k * n + j] = -fp->gain * sol[j];
+    }
+    *k_done = k;
+    return status;
+}
+
+void uvs_oracle_replay_batch(const oracle_params *fp, int64_t T, const double *f_seq, const double *dq_seq, const double *x0, double *x_log,
+                             double *cmd_log, double *kappa_log, int32_t *status, int32_t *k_done, int32_t *fpi_log) {
+    const size_t K = fp->steps, m = fp->m, n = fp->n;
+    for (int64_t t = 0; t < T; ++t)
+        status[t] = uvs_oracle_replay(fp, f_seq + t * (K + 1) * m, dq_seq + t * K * n, x0 + t * m * n, x_log ? x_log + t * K * m * n : 0,
+                                      cmd_log ? cmd_log + t * K * n : 0, kappa_log ? kappa_log + t * K * m : 0, k_done + t, fpi_log ? fpi_log + t * K : 0);
 }
 
 /* Batch driver: trials t = 0..T-1 with per-trial q_start [T][n], noise [T][K][m]; outputs [T][K][...] (may be NULL). */

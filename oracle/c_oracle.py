@@ -71,3 +71,23 @@ def closed_loop_batch(q_start, noise, desired, method='GMCKF', kernel_bw=10.0, a
     fn.restype, fn.argtypes = None, [C.POINTER(Params), C.POINTER(Plant), C.c_int64] + [C.c_void_p] * 9
     fn(C.byref(fp), C.byref(pl), T, ptr(q_start), ptr(noise), ptr(err), ptr(q), ptr(X), ptr(stats), ptr(status), ptr(k_done), ptr(fpi))
     return dict(err=err, q=q, X=X, stats=stats, status=status, k_done=k_done, fpi=fpi)
+
+
+def replay_batch(f_seq, dq_seq, x0, desired, method='GMCKF', kernel_bw=10.0, annealing=False, k_max=300, gain=0.2, fpi_threshold=0.1, fpi_epoch_max=1000):
+    """f_seq (T, K+1, m), dq_seq (T, K, n), x0 (T, m n) -> dict(X (T,K,mn), dq_cmd (T,K,n), kappa (T,K,m), status, k_done, fpi (T,K))."""
+    f_seq, dq_seq, x0 = (np.ascontiguousarray(a, float) for a in (f_seq, dq_seq, x0))
+    T, K, n = dq_seq.shape
+    m = f_seq.shape[2]
+    fp = Params()
+    fp.m, fp.n, fp.method, fp.annealing, fp.k_max, fp.steps, fp.initial_guess = m, n, METHOD[method], int(annealing), int(k_max), K, 0
+    fp.kernel_bw, fp.anneal_span, fp.gain, fp.dt, fp.reg = kernel_bw, 100.0, gain, 0.0, 0.001 ** 2
+    fp.fpi_threshold, fp.fpi_epoch_max = fpi_threshold, fpi_epoch_max
+    for i, v in enumerate(desired):
+        fp.desired[i] = v
+    X, cmd, kap = np.zeros((T, K, m * n)), np.zeros((T, K, n)), np.zeros((T, K, m))
+    status, k_done, fpi = np.zeros(T, np.int32), np.zeros(T, np.int32), np.zeros((T, K), np.int32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    fn = lib().uvs_oracle_replay_batch
+    fn.restype, fn.argtypes = None, [C.POINTER(Params), C.c_int64] + [C.c_void_p] * 9
+    fn(C.byref(fp), T, ptr(f_seq), ptr(dq_seq), ptr(x0), ptr(X), ptr(cmd), ptr(kap), ptr(status), ptr(k_done), ptr(fpi))
+    return dict(X=X, dq_cmd=cmd, kappa=kap, status=status, k_done=k_done, fpi=fpi)

@@ -213,3 +213,28 @@ def test_experiment_api_drop_in_fpi(uvs, name, route):
     for got, ref in ((err, g['err']), (q, g['q']), (f, g['f'])):
         assert rel_err(got, ref) <= tol
     assert np.array_equal(bw, g['sigma_log'])
+
+
+@pytest.mark.parametrize('lanes', [0, 4, -2])
+def test_infinite_sample_is_a_skipped_correction_for_mckf(uvs, lanes):
+    """An infinite measurement: Cy = exp(-inf) = 0, inv(Cy) raises and MCKF keeps only the prediction of that step (experiment.py:225-236) -- the
+    state survives (found by tools/fuzz_replay.py: the kernels formed 0 * inf in the state update).  The trial still ends one step later,
+    when the infinite error has gone through the control law into the joints; KF / IMCC-KF / RMCKF lose X at the step itself.  Both as the
+    reference's restatements do (oracle/c here; the dense numpy port agrees)."""
+    from oracle import c_oracle
+    g = load_golden('closed_mckf_a1p5')
+    meta = g['meta']
+    K = 40
+    noise = np.repeat(g['noise'][:K, :, None], 3, axis=2).copy()
+    noise[11, 2, 1] = np.inf                                                  # trial 1 only
+    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    for method, k_fail in (('MCKF', 12), ('GMCKF', 11), ('KF', 11)):
+        ref = c_oracle.closed_loop_batch(np.tile(g['q_start'], (3, 1)), noise.transpose(2, 0, 1), g['desired'], method, steps=K)
+        assert ref['status'].tolist() == [0, 1, 0] and ref['k_done'].tolist() == [K, k_fail, K]
+        fp = uvs.engine.make_params(8, 6, method, 10, False, meta['dt'], meta['t_max'], meta['gain'], g['desired'], True, lanes, K)
+        out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(np.tile(g['q_start'], (3, 1))), _cuda(noise), want=('x', 'err'))
+        assert out['status'].cpu().tolist() == [0, 1, 0] and out['k_done'].cpu().tolist() == [K, k_fail, K], method
+        X = out['x'].cpu().numpy()
+        assert np.array_equal(X[:, :, 0], X[:, :, 2]) and rel_err(X[:11, :, 1], X[:11, :, 0]) <= 1e-12
+        if method == 'MCKF':
+            assert np.all(np.isfinite(X[11, :, 1])) and rel_err(X[11, :, 1], X[10, :, 1]) <= 1e-15    # skipped correction: X unchanged

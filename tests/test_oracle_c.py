@@ -49,3 +49,19 @@ def test_c_oracle_reproduces_reference_fpi(name):
     tol = 1e-7 if name == 'fpi_mckf_a1p2_cap4' else 1e-9
     assert rel_err(out['err'][0, :k], g['err']) <= tol and rel_err(out['q'][0, :k], g['q']) <= tol
     assert rel_err(out['X'][0, g['X_steps']], g['X']) <= tol
+
+
+@pytest.mark.parametrize('name', CLOSED + FPI)
+def test_c_oracle_replay_reproduces_reference(name):
+    """Open-loop replay in plain C (uvs_oracle_replay): the reference's recorded f / regressor streams in, its per-step X and commands out."""
+    g = load_golden(name)
+    meta, p = g['meta'], g['meta']['params']
+    k = len(g['t'])
+    f_seq = np.vstack([g['f_init'][None], g['f']])
+    out = c_oracle.replay_batch(f_seq[None], g['dq_prev'][None], g['X'][0][None], g['desired'], meta['method'], p['kernel_bw'], p['annealing'],
+                                int(meta['t_max'] / meta['dt']), meta['gain'], p['fpi_threshold'], p['fpi_epoch_max'])
+    assert out['status'][0] == 0 and out['k_done'][0] == k
+    assert rel_err(out['X'][0, g['X_steps']], g['X']) <= 1e-10
+    assert rel_err(out['dq_cmd'][0, :-1], g['dq_prev'][1:]) <= 1e-8
+    if 'fpi_epochs' in g:
+        assert np.array_equal(out['fpi'][0], g['fpi_epochs'][:k])

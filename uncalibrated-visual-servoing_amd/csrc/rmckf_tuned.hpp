@@ -142,7 +142,7 @@ UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
     for (int r = 0; r < R; ++r) {
         const double a = arg_of_row(r);
         zero |= a < kExpZeroBelow;
-        unsure |= !(a < kExpZeroBelow) && !(a > kExpNonzeroAbove);    // NaN lands here as well; the finiteness probe FAILs the trial anyway
+        unsure |= (a >= kExpZeroBelow) && (a <= kExpNonzeroAbove);    // (a NaN argument is not "unsure": that trial FAILs by itself, no second pass)
         poison |= a < kRcpOverflowArg;                                // decided on the argument: no weight has to stay live for it
     }
     fpi.skip = zero;
@@ -376,7 +376,10 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         for (int j = 0; j < N; ++j) share.g[j] = g[j];
         share.gamma = gamma;
     }
-    const double step = gamma * nu;
+    // MCKF: an INFINITE innovation (a non-finite feature reached the filter) gives Cy = 0, inv(Cy) raises in the reference and the step keeps only
+    // the prediction (gamma = 0 above) -- the state survives.  0 * inf must not turn it into NaN here: the innovation is clamped to the largest
+    // finite value for the product (two instructions; a NaN innovation still arrives as a NaN gain and FAILs the trial as in the reference).
+    const double step = (METHOD == UVS_METHOD_MCKF) ? gamma * fmax(fmin(nu, 1.7976931348623157e308), -1.7976931348623157e308) : gamma * nu;
     const double beta = gamma * (2.0 - gamma * (a + 1.0));
 #pragma unroll
     for (int j = 0; j < N; ++j) {
