@@ -37,6 +37,8 @@ typedef struct {
     double theta_offset[MAXN], d[MAXN], a[MAXN], alpha[MAXN];
     double points[MAXPTS][3];
     double focal, center;
+    /* linear consistent plant f = lin_f0 + lin_J (q - lin_q0) (BASELINE config 5: no DH model at m = 32, n = 7); used when lin_J != NULL */
+    const double *lin_J, *lin_f0, *lin_q0;
 } oracle_plant;
 
 static double gaussian_kernel(double e, double bw) { return exp(-0.5 * (e * e) / (bw * bw)); }
@@ -348,8 +350,15 @@ int uvs_oracle_closed_loop(const oracle_params *fp, const oracle_plant *pl, cons
     int status = 0, k = 0;
     for (; k < K; ++k) {
         memcpy(f_old, f, sizeof(double) * m);
-        fkine_all(pl, q, T);
-        features(pl, T[n - 1], f);
+        if (pl->lin_J) {
+            for (int i = 0; i < m; ++i) {
+                f[i] = pl->lin_f0[i];
+                for (int j = 0; j < n; ++j) f[i] += pl->lin_J[i * n + j] * (q[j] - pl->lin_q0[j]);
+            }
+        } else {
+            fkine_all(pl, q, T);
+            features(pl, T[n - 1], f);
+        }
         if (noise)
             for (int i = 0; i < m; ++i) f[i] += noise[k * m + i];
         double kappa[MAXM], err[MAXM];

@@ -19,7 +19,8 @@ class Params(C.Structure):
 
 class Plant(C.Structure):
     _fields_ = [('n_joints', C.c_int32), ('n_points', C.c_int32), ('theta_offset', C.c_double * 8), ('d', C.c_double * 8),
-                ('a', C.c_double * 8), ('alpha', C.c_double * 8), ('points', (C.c_double * 3) * 16), ('focal', C.c_double), ('center', C.c_double)]
+                ('a', C.c_double * 8), ('alpha', C.c_double * 8), ('points', (C.c_double * 3) * 16), ('focal', C.c_double), ('center', C.c_double),
+                ('lin_J', C.c_void_p), ('lin_f0', C.c_void_p), ('lin_q0', C.c_void_p)]
 
 
 _lib = None
@@ -48,15 +49,25 @@ def ur10_plant():
     return pl
 
 
+def linear_plant(J, f0, q0):
+    """f = f0 + J (q - q0): the consistent linearised camera of BASELINE config 5.  Keeps the arrays alive on the returned struct."""
+    pl = Plant()
+    J, f0, q0 = (np.ascontiguousarray(a, float) for a in (J, f0, q0))
+    pl.n_joints, pl.n_points = J.shape[1], J.shape[0] // 2
+    pl._keep = (J, f0, q0)
+    pl.lin_J, pl.lin_f0, pl.lin_q0 = (a.ctypes.data for a in (J, f0, q0))
+    return pl
+
+
 def closed_loop_batch(q_start, noise, desired, method='GMCKF', kernel_bw=10.0, annealing=False, dt=0.05, t_max=15.0, gain=0.2,
-                      steps=None, want_x=False, plant=None, fpi_threshold=0.1, fpi_epoch_max=1000):
+                      steps=None, want_x=False, plant=None, fpi_threshold=0.1, fpi_epoch_max=1000, x0=None):
     """q_start (T, n), noise (T, K, m) -> dict(err (T,K,m), q (T,K,n), X (T,K,mn)?, stats (T,3), status, k_done, fpi (T,K) MCKF passes per step)."""
     q_start, noise = np.ascontiguousarray(q_start, float), np.ascontiguousarray(noise, float)
     T, K, m = noise.shape
     n = q_start.shape[1]
     fp = Params()
     fp.m, fp.n, fp.method, fp.annealing, fp.k_max = m, n, METHOD[method], int(annealing), int(t_max / dt)
-    fp.steps, fp.initial_guess = K if steps is None else steps, 1
+    fp.steps, fp.initial_guess = K if steps is None else steps, int(x0 is None)
     fp.kernel_bw, fp.anneal_span, fp.gain, fp.dt, fp.reg = kernel_bw, 100.0, gain, dt, 0.001 ** 2
     fp.fpi_threshold, fp.fpi_epoch_max = fpi_threshold, fpi_epoch_max
     for i, v in enumerate(desired):
@@ -67,6 +78,14 @@ def closed_loop_batch(q_start, noise, desired, method='GMCKF', kernel_bw=10.0, a
     stats, status, k_done = np.zeros((T, 3)), np.zeros(T, np.int32), np.zeros(T, np.int32)
     fpi = np.zeros((T, fp.steps), np.int32)
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)     # noqa: E731
+    if x0 is not None:                                            # supplied X0 (the same for every trial or one row per trial): one trial at a time
+        x0 = np.ascontiguousarray(np.broadcast_to(np.asarray(x0, float).reshape(-1, m * n), (T, m * n)))
+        one = lib().uvs_oracle_closed_loop
+        one.restype, one.argtypes = C.c_int, [C.POINTER(Params), C.POINTER(Plant)] + [C.c_void_p] * 9
+        at = lambda a, t: None if a is None else C.c_void_p(a[t:t + 1].ctypes.data)     # noqa: E731
+        for t in range(T):
+            status[t] = one(C.byref(fp), C.byref(pl), at(q_start, t), at(noise, t), at(x0, t), at(err, t), at(q, t), at(X, t), at(stats, t), at(k_done, t), at(fpi, t))
+        return dict(err=err, q=q, X=X, stats=stats, status=status, k_done=k_done, fpi=fpi)
     fn = lib().uvs_oracle_closed_loop_batch
     fn.restype, fn.argtypes = None, [C.POINTER(Params), C.POINTER(Plant), C.c_int64] + [C.c_void_p] * 9
     fn(C.byref(fp), C.byref(pl), T, ptr(q_start), ptr(noise), ptr(err), ptr(q), ptr(X), ptr(stats), ptr(status), ptr(k_done), ptr(fpi))

@@ -37,14 +37,25 @@ def main():
             for c in range(3):
                 pl.points[i][c] = w[c]
         shapes[m] = (des, host.to_struct(), pl)
+    lin = uvs.LinearPlant.random(32, 7, seed=2)                   # the wide stress shape (BASELINE config 5): consistent linear plant, X0 supplied
+    lrng = np.random.default_rng(5)
+    q_goal = lin.q0 + lrng.uniform(-0.3, 0.3, 7)
+    wide = dict(desired=lin.features(q_goal), q_goal=q_goal, x0=(lin.J * (1 + 0.1 * lrng.normal(size=lin.J.shape))).ravel(),
+                struct=lin.to_struct('cuda'), pl=c_oracle.linear_plant(lin.J, lin.f0, lin.q0))
     worst, bad, n_calm, n_all, n_fail, n_multi = 0.0, [], 0, 0, 0, 0
     t0 = time.time()
     for case in range(cases):
         method = ['GMCKF', 'KF', 'IMCCKF', 'MCKF'][case % 4]
-        m = int(rng.choice([8, 8, 8, 6, 2]))
-        desired, plant, pl = shapes[m]
-        lane = int(rng.choice(lanes_of[method])) if m == 8 else int(rng.choice({6: [0, 2, 1], 2: [0, 1]}[m]))
-        T = int(rng.integers(1, 200))
+        m = int(rng.choice([8, 8, 8, 6, 2, 32]))
+        n = 7 if m == 32 else 6
+        if m == 32:
+            desired, plant, pl = wide['desired'], wide['struct'], wide['pl']
+            lane = int(rng.choice([0, 8, 16, 32, -8, -16])) if method != 'MCKF' else int(rng.choice([16, -16, 32]))      # MCKF: generic template only
+        else:
+            desired, plant, pl = shapes[m]
+            lane = int(rng.choice(lanes_of[method])) if m == 8 else int(rng.choice({6: [0, 2, 1], 2: [0, 1]}[m]))
+        layout = 'ktc' if (m == 32 and rng.random() < 0.6) else 'kct'
+        T = int(rng.integers(1, 200)) if m != 32 else int(rng.choice([1, 7, 8, 9, 40, 64, 77]))
         K = int(rng.integers(1, 120))
         dt = float(rng.choice([0.02, 0.05, 0.1]))
         t_max = dt * (K + 1) + (dt / 2 if rng.random() < 0.5 else 5.0)
@@ -57,17 +68,25 @@ def main():
                  'cauchy': lambda: rng.standard_cauchy(size=(T, K, m)), 'normal': lambda: rng.standard_normal((T, K, m)),
                  'none': lambda: np.zeros((T, K, m))}[law]() * scale
         thr, cap = float(rng.choice([0.1, 1e-2, 1e-4])), int(rng.choice([1, 2, 5, 1000]))
-        q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
-        q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
-        kw = dict(method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True, fpi_threshold=thr, fpi_epoch_max=cap, plant=pl)
+        if m == 32:
+            q0 = wide['q_goal'] + rng.uniform(-0.15, 0.15, (T, 7))
+            scale *= 0.3
+            noise *= 0.3
+        else:
+            q0 = np.tile(cfg['experiments']['q_start'], (T, 1)).astype(float)
+            q0[:, :3] += rng.uniform(-0.15, 0.15, (T, 3))
+        if K > 4 and T > 2 and rng.random() < 0.15:               # a non-finite sample somewhere: FAIL (or, for MCKF and inf, a skipped correction)
+            noise[T // 2, K // 2, 0] = np.inf if rng.random() < 0.7 else np.nan
+        kw = dict(method=method, kernel_bw=bw, annealing=anneal, dt=dt, t_max=t_max, gain=gain, steps=K, want_x=True, fpi_threshold=thr, fpi_epoch_max=cap, plant=pl, x0=(wide['x0'] if m == 32 else None))
         ref = c_oracle.closed_loop_batch(q0, noise, desired, **kw)
         ref2 = c_oracle.closed_loop_batch(q0 * (1.0 + 1e-14), noise, desired, **kw)
-        fp = uvs.engine.make_params(m, 6, method, bw, anneal, dt, t_max, gain, desired, True, lane, K, thr, cap)
-        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0)), device='cuda'),
-                                     want=('x', 'err', 'q'))
+        fp = uvs.engine.make_params(m, n, method, bw, anneal, dt, t_max, gain, desired, m != 32, lane, K, thr, cap)
+        nz_dev = torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0) if layout == 'kct' else noise.transpose(1, 0, 2)), device='cuda')
+        x0_dev = torch.as_tensor(np.tile(wide['x0'], (T, 1)), device='cuda') if m == 32 else None
+        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), nz_dev, x0_dev, want=('x', 'err', 'q'), layout=layout)
         st, kd = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
-        X, E, Q = (out[k].cpu().numpy().transpose(2, 0, 1) for k in ('x', 'err', 'q'))
-        tag = (case, m, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
+        X, E, Q = (uvs.engine.as_tkc(out[k], layout).cpu().numpy() for k in ('x', 'err', 'q'))
+        tag = (case, m, layout, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
         n_fail += int((ref['status'] == 1).sum())
         if method == 'MCKF':
             n_multi += int((ref['fpi'] >= 2).sum())
