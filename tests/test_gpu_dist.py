@@ -127,12 +127,12 @@ def test_bench_two_ranks_by_name(scaling):
 
 
 @pytest.mark.timeout(900)
-def test_bench_four_ranks_strong_series():
-    """Four gloo ranks sharing the GPU (the card allows six processes): north_star's strong series at a total the card holds four times over,
-    ragged shards (4 099 = 1 025 + 1 025 + 1 025 + 1 024)."""
-    d = _torchrun_bench(4, '--backend', 'gloo', '--trials', '4099')
-    assert d['n_gpus'] == 4 and d['scaling'] == 'strong' and d['config']['trials_total'] == 4099 and d['config']['ranks_seen'] == 4
-    assert d['config']['trials_rank0'] == 1025 and d['config']['failed_trials'] == 0
+def test_bench_three_ranks_strong_series():
+    """Three gloo ranks sharing the GPU (the box allows six processes on the card: three ranks + the launcher + this test process leave a
+    margin): north_star's strong series at a total the card holds three times over, ragged shards (4 099 = 1 367 + 1 366 + 1 366)."""
+    d = _torchrun_bench(3, '--backend', 'gloo', '--trials', '4099')
+    assert d['n_gpus'] == 3 and d['scaling'] == 'strong' and d['config']['trials_total'] == 4099 and d['config']['ranks_seen'] == 3
+    assert d['config']['trials_rank0'] == 1367 and d['config']['failed_trials'] == 0
     assert abs(d['value'] - 4099 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     assert d['multi_gpu']['kernel_ms_avg_over_ranks']['max'] >= d['multi_gpu']['kernel_ms_avg_over_ranks']['min'] > 0
 
