@@ -529,6 +529,9 @@ struct PlantLds {
 // With L = 4 the whole state fits the 256 VALU-addressable registers (P: 84, X: 24), LDS holds only the statistics and
 // the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
 // issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
+#ifdef UVS_PERSISTENT
+__device__ unsigned g_uvs_work_counter;                  // experiment build only: next work item of the persistent grid (reset by the launcher)
+#endif
 #ifndef UVS_INC_SINCOS                  // experiment builds: 0 = sincos of every joint angle from scratch every step (round-2 code)
 #define UVS_INC_SINCOS 1
 #endif
@@ -570,7 +573,19 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
     const int grp = SPLIT ? (sub < G ? sub : G - 1) : 0;           // with L = 4 the fourth lane mirrors group 2
-#ifdef UVS_WAVE_TIMES                   // experiment: workgroup -> trial-chunk mappings (A.fp.reserved selects; 0 = identity)
+#ifdef UVS_PERSISTENT                   // experiment build: a persistent grid (as many wavefronts as the chip holds) pulling 64 / L-trial work
+    for (;;) {                          // items from a global atomic counter instead of one workgroup per item (measured, not shipped)
+        unsigned item_ = 0;
+        if (lane == 0) item_ = atomicAdd(&g_uvs_work_counter, 1u);
+        item_ = (unsigned)__builtin_amdgcn_readfirstlane((int)item_);
+        if ((long long)item_ * TPW >= A.T) break;
+        const long long wave_first = (long long)item_ * TPW;
+#ifdef UVS_WAVE_TIMES
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
+#endif
+#define UVS_ITEM_END continue
+#elif defined(UVS_WAVE_TIMES)           // experiment: workgroup -> trial-chunk mappings (A.fp.reserved selects; 0 = identity)
+#define UVS_ITEM_END return
     long long chunk = blockIdx.x;
     {
         const long long nw = gridDim.x, nfull = (nw / 8) * 8;
@@ -578,6 +593,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     }
     const long long wave_first = chunk * TPW;
 #else
+#define UVS_ITEM_END return
     const long long wave_first = (long long)blockIdx.x * TPW;      // first trial of this wavefront (uniform)
 #endif
     const unsigned tl = lane / L;                                   // trial within the wavefront
@@ -1183,7 +1199,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
-    if (!valid) return;
+    if (!valid) UVS_ITEM_END;
     if (sub == 0) {
         if (A.stats) {
 #pragma unroll
@@ -1223,6 +1239,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                         SHARED_P ? p[0][Sym<N>::at(l, j)]
                                  : (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }
+#ifdef UVS_PERSISTENT
+    }                                   // next work item
+#endif
+#undef UVS_ITEM_END
 }
 
 }  // namespace uvs
