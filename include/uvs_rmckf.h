@@ -202,7 +202,7 @@ int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t
 /*
  * Test hook: evaluates the library's fp64 helper functions on the device so that tests can bound their error against
  * numpy.  which: 0 fast reciprocal, 1 sqrt, 2 rsqrt, 3 sin, 4 cos (bounded-argument sincos with library fallback), 5 exp,
- * 6 exp for non-positive arguments.
+ * 6 exp for non-positive arguments, 7 log (own routine on normal positive arguments, library elsewhere), 8 exp with clamped argument.
  */
 int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
 

@@ -51,3 +51,34 @@ def test_exp_on_kernel_range():
     got = _eval(6, edge)
     assert got[0] == 1.0 and got[1] == 1.0 and got[2] == 1.0 and np.all(got[4:] == 0.0) and abs(got[3] / np.exp(-745.0) - 1) < 1e-3
     assert np.isnan(_eval(6, np.array([np.nan]))[0])
+
+
+def test_log_own_routine_and_fallback():
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(0, 1, 300000), np.exp(rng.uniform(-708, 709, 300000)), -np.log(rng.uniform(0, 1, 200000)),
+                        1.0 + rng.uniform(-0.5, 0.5, 200000) * 10.0 ** rng.uniform(-15, 0, 200000),
+                        np.cos(rng.uniform(-np.pi / 2, np.pi / 2, 200000)), [1.0, 2.0, 0.5, 2.2250738585072014e-308, 1.7976931348623157e308]])
+    x = x[(x >= 2.2250738585072014e-308) & np.isfinite(x)]
+    got, ref = _eval(7, x), np.log(x)
+    nz = ref != 0
+    assert _ulps(got[nz], ref[nz]).max() <= 1.5 and np.all(got[~nz] == 0.0)
+    # zero, subnormal, negative, non-finite: the library's results (numpy's semantics)
+    edge = np.array([0.0, -0.0, 5e-324, 1e-310, -1.0, np.inf, -np.inf, np.nan])
+    with np.errstate(all='ignore'):
+        want = np.log(edge)
+    got = _eval(7, edge)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    fin = ~np.isnan(want)
+    assert np.all((got[fin] == want[fin]) | (_ulps(got[fin], want[fin]) <= 1.0))
+
+
+def test_exp_clamped_full_range():
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-745, 709.7, 300000), rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-12, 0, 100000)])
+    assert _ulps(_eval(8, x), np.exp(x)).max() <= 2.0
+    edge = np.array([0.0, 709.78, 709.79, 800.0, 1e300, np.inf, -746.0, -1e300, -np.inf])
+    got = _eval(8, edge)
+    with np.errstate(all='ignore'):
+        want = np.exp(edge)
+    assert got[0] == 1.0 and abs(got[1] / want[1] - 1) < 1e-14 and np.all(np.isinf(got[2:6])) and np.all(got[6:] == 0.0)
+    assert np.isnan(_eval(8, np.array([np.nan]))[0])

@@ -106,3 +106,19 @@ def test_device_cms_matches_host_generator_outside_the_fixtures(uvs, alpha, beta
     assert finite.mean() > 0.999 and np.array_equal(np.isfinite(dev), finite)
     scale = np.maximum(np.abs(host[finite]), 1e-3)                           # delta shifts values through zero: relative to max(|x|, 1e-3)
     assert np.max(np.abs(dev[finite] - host[finite]) / scale) <= 5e-13
+
+
+@pytest.mark.parametrize('alpha', [0.05, 0.3, 0.75, 1.0909090909090908, 1.5, 1.9090909090909092, 1.99, 1.9999])
+def test_symmetric_stable_fast_path_and_its_gate(uvs, alpha):
+    """beta = 0: the specialised instantiation (own log / exp routines, cos((1 - alpha) V) by the addition theorem) where the launcher's
+    error bound admits it (0.3 ... 1.99 here), the general kernel elsewhere (0.05, 1.9999) -- 400 k samples each against the host
+    NoiseProfiler port at the gate of the reference fixtures."""
+    params = dict(alpha=alpha, beta=0.0, gamma=1.0, delta=0.0)
+    seeds = list(range(5000, 5128))
+    K = 400
+    dev = uvs.engine.as_tkc(uvs.noise_device.generate(uvs.NoiseType.ALPHA_STABLE, params, seeds, 8, K), 'kct').cpu().numpy()
+    host = uvs.noise_batch(uvs.NoiseType.ALPHA_STABLE, params, seeds, 8, K)
+    finite = np.isfinite(host)
+    assert finite.mean() > 0.999 and np.array_equal(np.isfinite(dev), finite)
+    rel = np.abs(dev[finite] - host[finite]) / np.abs(host[finite])
+    assert rel.max() <= 2e-13, (alpha, rel.max())

@@ -10,7 +10,7 @@ import os
 import re
 import sys
 
-ASM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'uncalibrated-visual-servoing_amd', 'csrc', 'uvs_rmckf.gfx950.s')
+ASM = os.environ.get("UVS_ASM", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uncalibrated-visual-servoing_amd", "csrc", "uvs_rmckf.gfx950.s"))
 
 
 def classify(op):

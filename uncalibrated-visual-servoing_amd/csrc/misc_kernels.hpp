@@ -43,6 +43,8 @@ __global__ __launch_bounds__(256) void debug_math_kernel(int which, long long n,
         case 3: sincos_any(v, s, c); y[i] = s; break;
         case 4: sincos_any(v, s, c); y[i] = c; break;
         case 6: y[i] = exp_nonpos(v); break;
+        case 7: y[i] = log_any(v); break;
+        case 8: y[i] = exp_clamped(v); break;
         default: y[i] = exp(v); break;
     }
 }

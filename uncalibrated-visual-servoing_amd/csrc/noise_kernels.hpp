@@ -123,9 +123,39 @@ UVS_DEV double standard_normal(Pcg64 &g, const double *zig) {
 // One fresh sample of feature `i` (noise.py:120-207).  gens[]: this feature's main generators (component 0, 1, 2), sel: selector.
 // TYPE: the noise type, fixed at compile time (each instantiation carries only the generators and the code of its own type; with the type
 // chosen at run time every lane held 8 generator states = 64 registers and the kernel ran two wavefronts per SIMD).
+// Kernel-internal noise type: ALPHA_STABLE with beta = 0 and alpha not in {0.5 (|beta| = 1), 1, 2} -- the reference's own sweeps
+// (config.json: alpha = linspace(1, 2, 12), beta = 0).  The launcher selects it; the step loop then carries none of the run-time
+// case analysis on (alpha, beta), which costs the general instantiation registers, scalar moves and branches on every sample.
+constexpr int kNoiseStableSymmetric = 6;
+
+// Whether the symmetric instantiation's addition-theorem cosine is accurate enough for these parameters (see draw_stable_symmetric).
+inline bool stable_symmetric_fast(const uvs_noise_params &p) {
+    if (!(p.beta == 0.0 && p.alpha != 1.0 && p.alpha != 2.0 && p.alpha > 0.0 && p.alpha < 2.0)) return false;   // (alpha = 0.5 is special only with |beta| = 1: noise.py:185)
+    const double floor_c2 = cos(fabs(1.0 - p.alpha) * 1.5707963267948966);
+    return fabs(p.expo) * 2.0e-16 <= 2.0e-14 * floor_c2;
+}
+
+// The general Chambers-Mallows-Stuck draw for beta = 0 (noise.py:188-192): see the comments in draw<> below.
+UVS_DEV double draw_stable_symmetric(const uvs_noise_params &p, Pcg64 &g) {
+    const double HALF_PI = 1.5707963267948966, PI = 3.141592653589793;
+    const double V = -HALF_PI + PI * g.next_double();
+    const double W = -log_any(0.0 + 1.0 * g.next_double());
+    double s1, c1, s0, c0;
+    sincos_bounded(p.alpha * V, s1, c1);
+    sincos_bounded(V, s0, c0);
+    // cos((1 - alpha) V) = cos(V - alpha V) by the addition theorem: two instructions instead of a third sincos.  Its absolute error of
+    // ~2e-16 is a relative one of 2e-16 / cos(|1 - alpha| pi / 2) at worst, which enters the sample times |(1 - alpha) / alpha|; the launcher
+    // selects this kernel only where that product stays below 2e-14 (stable_symmetric_fast below), a tenth of the noise fixtures' gate.
+    const double c2 = fma(s0, s1, c0 * c1);
+    const double ratio = __builtin_expect(W <= 1.0e300, 1) ? c2 * fast_rcp(W) : c2 / W;
+    const double e = exp_clamped(fma(p.expo, log_any(ratio), -p.inv_alpha * log_any(c0)));
+    return p.gamma * (s1 * e) + p.delta;
+}
+
 template <int TYPE>
 UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const double *zig) {
     const double HALF_PI = 1.5707963267948966, PI = 3.141592653589793;
+    if constexpr (TYPE == kNoiseStableSymmetric) return draw_stable_symmetric(p, gens[0]);
     switch (TYPE) {
         case UVS_NOISE_WHITE: return 0.0 + p.std * standard_normal(gens[0], zig);
         case UVS_NOISE_UNIFORM: return gens[0].next_double();                              // uniform(): 0 + 1 * u
@@ -153,12 +183,14 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
         x = p.beta / (z * z);
     } else {
         const double V = -HALF_PI + PI * gens[0].next_double();
-        const double W = -log(0.0 + 1.0 * gens[0].next_double());
+        const double W = -log_any(0.0 + 1.0 * gens[0].next_double());     // 1.1e-16 <= W <= 36.8, or +inf for a zero draw (probability 2^-53)
         if (p.alpha != 1.0) {
             // sin(aV + B) / cos(V)^(1/a) * (cos((1-a)V - B) / W)^((1-a)/a), B = 0 and S = 1 when beta = 0 (noise.py:188-199).  The two powers
             // are folded into one exponential, exp(e log(c2 / W) - log(c1) / a): three bounded-argument sincos (|angle| < 3 pi / 2), two logs
             // and one exp instead of three trigonometric calls and two pow(); differs from the reference's evaluation by
             // <= (|exponent| + 2) ulp (|exponent| <~ 40 even for the 1e-16 tails of cos V and W), inside the 2e-13 gate of the noise fixtures.
+            // The logs and the exp are this library's own short routines (rmckf_math.hpp: 33 and 21 instructions against ~85 and ~30 of the
+            // extended-precision library ones; same <= 1.5 ulp); zero / negative / non-finite arguments take the library's.
             // A negative base (possible only with beta != 0) gives NaN through log exactly as numpy's pow does.
             const bool sym = (p.beta == 0.0);
             const double B = sym ? 0.0 : p.cms_B;
@@ -166,7 +198,9 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
             sincos_bounded(sym ? p.alpha * V : p.alpha * V + B, s1, c1);
             sincos_bounded(V, s0, c0);
             sincos_bounded(sym ? V * p.one_minus_alpha : p.one_minus_alpha * V - B, s2, c2);
-            const double e = exp(fma(p.expo, log(c2 / W), -p.inv_alpha * log(c0)));
+            // (c2 / W as c2 * (1 / W): W is normal and positive unless the draw was zero, which takes the division)
+            const double ratio = __builtin_expect(W <= 1.0e300, 1) ? c2 * fast_rcp(W) : c2 / W;
+            const double e = exp_clamped(fma(p.expo, log_any(ratio), -p.inv_alpha * log_any(c0)));
             x = sym ? s1 * e : p.cms_S * s1 * e;
         } else {
             const double sv = HALF_PI + p.beta * V;
@@ -176,8 +210,13 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
     return (p.alpha == 1.0) ? p.gamma * x + p.shift + p.delta : p.gamma * x + p.delta;
 }
 
+#ifdef UVS_NOISE_WAVES                  // experiment builds: pin the occupancy the register allocator aims at
+#define UVS_NOISE_OCC __attribute__((amdgpu_waves_per_eu(UVS_NOISE_WAVES, UVS_NOISE_WAVES)))
+#else
+#define UVS_NOISE_OCC
+#endif
 template <int TYPE>
-__global__ __launch_bounds__(64) void noise_kernel(const NoiseArgs A) {
+__global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_kernel(const NoiseArgs A) {
     const uvs_noise_params &p = A.np;
     const int pairs = p.m / 2;
     const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;

@@ -28,7 +28,12 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
         case UVS_NOISE_WHITE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_WHITE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_GAUSSIAN_MIXTURE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_MIXTURE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_GAUSSIAN_BIMODAL: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_BIMODAL>, g, dim3(64), 0, s, A); break;
-        case UVS_NOISE_ALPHA_STABLE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A); break;
+        case UVS_NOISE_ALPHA_STABLE:
+            if (uvs::stable_symmetric_fast(np))
+                hipLaunchKernelGGL(uvs::noise_kernel<uvs::kNoiseStableSymmetric>, g, dim3(64), 0, s, A);
+            else
+                hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A);
+            break;
         default: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_UNIFORM>, g, dim3(64), 0, s, A); break;
     }
 }
