@@ -305,10 +305,11 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     k_done = torch.zeros(T, dtype=torch.int32, device=dev)
     q0_all = torch.as_tensor(plan.q_start.copy(), device=dev)
     nt = uvs_amd.NoiseType.ALPHA_STABLE
+    seeds_dev = torch.as_tensor(np.asarray(plan.seed, dtype=np.uint64).view(np.int64), device=dev)     # every cell's seeds, uploaded once
 
     def gen(c, buf):
         params = dict(alpha=float(cells[c]), beta=0, gamma=1, delta=0)
-        uvs_amd.noise_device.generate(nt, params, plan.seed[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
+        uvs_amd.noise_device.generate(nt, params, seeds_dev[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
 
     def loop(c, buf, slot):
         rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(

@@ -23,6 +23,8 @@ plan = batch.plan_trials(cfg, cells=[1.5])
 noise = batch.device_noise(cfg, plan, 0, T, K, dev)
 q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
 plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+if args.reps > 1000:
+    open('gpurun_out/.probe_started', 'w').write('1')                # tools/power_probe.sh waits for this
 for meth in args.methods.split(','):
     fp = engine.make_params(8, 6, meth, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
     ms = []

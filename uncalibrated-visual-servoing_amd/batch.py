@@ -117,12 +117,14 @@ def device_noise(cfg, plan, lo, hi, steps, device='cuda'):
     hold_cnt = int(nz['hold_time'] / cfg['experiments']['dt'])      # main.py:137
     key = 'alpha' if noise_type == NoiseType.ALPHA_STABLE else 'rho'
     out = engine.alloc_stream(hi - lo, steps, m, 'kct', device)
+    torch = engine._torch()
+    seeds_dev = torch.as_tensor(np.ascontiguousarray(plan.seed[lo:hi], dtype=np.uint64).view(np.int64), device=device)   # one upload for the shard
     for c in np.unique(plan.cell[lo:hi]):
         idx = np.nonzero(plan.cell[lo:hi] == c)[0]                  # cells are contiguous runs of trials (main.py:121-127)
         params = dict(nz['noise_params'])
         params[key] = float(plan.cells[c])                          # main.py:123-126
         a, b = int(idx[0]), int(idx[-1]) + 1
-        noise_device.generate(noise_type, params, plan.seed[lo:hi][a:b], m, steps, nz['hold'], hold_cnt, 'kct', out=out[:, :, a:b], device=device)
+        noise_device.generate(noise_type, params, seeds_dev[a:b], m, steps, nz['hold'], hold_cnt, 'kct', out=out[:, :, a:b], device=device)
     return out
 
 
