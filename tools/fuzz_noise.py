@@ -2,7 +2,7 @@
 """Randomised cross-check of the on-device noise generator (uvs_noise_generate_f64 + uvs_pcg64_seed_u64) against the host restatement of the
 reference's NoiseProfiler (uvs_amd.noise.noise_batch, itself bit-exact against 16 fixtures of the unmodified noise.py): noise type, its
 parameters (alpha, beta, gamma, delta / std, mean, rho), feature count, hold on / off with random hold lengths, seeds up to 2^62, layouts.
-Uniform / normal / mixture streams must agree to the bit (normals: to 4e-16 on the rare wedge / tail samples), the transcendental
+Uniform / normal / mixture streams must agree to the bit (normals: to 2 ulp = 4.5e-16 on the rare wedge / tail samples, whose log1p / exp come from a different libm), the transcendental
 alpha-stable branches to 2e-13.   usage (GPU box): python tools/fuzz_noise.py [cases] [seed]"""
 import os
 import sys
@@ -29,6 +29,8 @@ def main():
         hold_cnt = int(rng.integers(1, 15))
         if kind == NT.ALPHA_STABLE:
             alpha = float(rng.choice([2.0, 1.0, 0.5, 1.5, 1.2, 1.0909090909090908, 0.8, 1.9]))
+            if rng.random() < 0.4:                               # any index: both sides of the launcher's error gate for the beta = 0 instantiation
+                alpha = float(rng.uniform(0.05, 1.9999))
             beta = float(rng.choice([0.0, 0.0, 0.5, -0.5, 1.0])) if alpha != 0.5 else float(rng.choice([1.0, -1.0, 0.0]))
             params = dict(alpha=alpha, beta=beta, gamma=float(rng.choice([1.0, 2.0, 0.5])), delta=float(rng.choice([0.0, 1.0, -3.0])))
         elif kind == NT.UNIFORM:
@@ -49,7 +51,7 @@ def main():
         scale = np.maximum(np.abs(host[fin]), 1e-300)
         d = np.abs(dev[fin] - host[fin]) / scale
         if exact_kind:
-            if np.mean(dev[fin] != host[fin]) > 2e-3 or (len(d) and d.max() > 4e-16):
+            if np.mean(dev[fin] != host[fin]) > 2e-3 or (len(d) and d.max() > 4.5e-16):
                 bad.append(('bits', tag, float(np.mean(dev[fin] != host[fin])), float(d.max())))
         else:
             atol = 1e-12 * (1 + abs(params.get('delta', 0.0)))                          # gamma x + delta cancels near 0
