@@ -281,6 +281,51 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4        # 256 CUs x 4 SIMDs, one wa
 FP64_VECTOR_PEAK_FLOPS = 78.6e12                     # MI355X_MICROARCH.md: fp64 vector peak
 
 
+def power_under_load(torch, launch, device_index, max_seconds=10.0):
+    """Package power and shader clock while the timed kernel runs back to back (side object, not part of the timed region): `rocm-smi`
+    sampled up to three times from a thread, after 0.6 s of settling, while this thread keeps the launch queue full.  The closed-loop kernel
+    is power-limited on MI355X: the clock it sustains, not the 2.4 GHz peak, is what its instruction rate sees.
+    Returns None when rocm-smi is missing or prints nothing parseable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(exe):
+        return None
+    samples, cap = [], [None]
+
+    def sampler():
+        time.sleep(0.6)
+        for _ in range(3):
+            try:
+                out = subprocess.run([exe, '-d', str(device_index), '--showpower', '--showclocks', '--showmaxpower'],
+                                     capture_output=True, text=True, timeout=20).stdout
+            except Exception:                                      # noqa: BLE001 -- a missing / hanging tool must not cost the bench line
+                return
+            w = re.search(r'(?:Current Socket|Average) Graphics Package Power \(W\):\s*([\d.]+)', out)
+            c = re.search(r'sclk clock level:\s*\S+\s*\((\d+)Mhz\)', out)
+            m = re.search(r'Max Graphics Package Power \(W\):\s*([\d.]+)', out)
+            if m:
+                cap[0] = float(m.group(1))
+            if w and c:
+                samples.append((float(w.group(1)), int(c.group(1))))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0, launches = time.perf_counter(), 0
+    while th.is_alive() and time.perf_counter() - t0 < max_seconds:
+        for _ in range(10):
+            launch()
+        torch.cuda.synchronize()
+        launches += 10
+    th.join(timeout=30)
+    if not samples:
+        return None
+    return {'package_watts': [w for w, _ in samples], 'sclk_mhz': [c for _, c in samples], 'cap_watts': cap[0], 'launches_while_sampling': launches,
+            'note': 'rocm-smi --showpower --showclocks sampled while the timed kernel ran back to back after the timed region; not part of `value`'}
+
+
 def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU):
     """What main.py:104-196 does for one sweep, end to end on the GPU (side object, never `value`): for each of the reference's 12 cells
     alpha = linspace(1, 2, 12) -- device seeding + noise generation, closed loop with X / err / q logged, D2H of the per-trial
@@ -388,6 +433,7 @@ def main():
     ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end sweep side object (counter passes: its 49 launches of the headline kernel on other noise would be averaged in)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
+    ap.add_argument('--no-power', action='store_true', help='skip the power / clock samples under load (about 3 s of extra launches)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
     ap.add_argument('--layout', default=None, choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams (default: trial-fastest kct; config 5: per-trial records ktc)')
@@ -572,6 +618,13 @@ def main():
                         'fp64_flops': (fl / (avg_ms * 1e-3)) if fl else None, 'fp64_peak_flops': FP64_VECTOR_PEAK_FLOPS,
                         'fp64_frac': (fl / (avg_ms * 1e-3) / FP64_VECTOR_PEAK_FLOPS) if fl else None,
                         'source': 'instruction counts per launch from the committed PMC passes (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64), divided by this run\'s kernel time'}
+        power = None
+        if world == 1 and not args.no_power:
+            power = power_under_load(torch, launch, torch.cuda.current_device())
+        if power and valu:                                         # the issue peak at the clock the part actually sustains under this kernel
+            clk = float(np.mean(power['sclk_mhz'])) * 1e6
+            valu['sustained_clock_hz'] = clk
+            valu['frac_at_sustained_clock'] = valu['wave_instr_per_s'] / (1024 * clk / 4)
         side_ok = world == 1 and headline_shape and not args.no_side
         replay = None
         if world == 1 and args.config == 2 and not args.no_replay and not args.e2e and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
@@ -637,8 +690,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned UR10 table),2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch,
-                         'binds': 'HBM is the roofline BASELINE.json prescribes; the counters say the kernel is bound by VALU issue at one wavefront per SIMD (see `valu`)',
-                         'valu': valu},
+                         'binds': 'HBM is the roofline BASELINE.json prescribes; the counters say the kernel is bound by VALU issue at one wavefront per SIMD (see `valu`), at the clock the package power cap leaves it (see `power`)',
+                         'valu': valu, 'power': power},
             'multi_gpu': {'kernel_ms_avg_over_ranks': rank_ms, 'gather_ms': gather_avg, 'gather_inside_timed_region': bool(dist_on), 'backend': args.backend if dist_on else None,
                           'gather_note': 'all_gather of per-trial [ISE, IAE, ITAE, status] rows (32 B/trial); nccl: HIP events on the launch stream, gloo: host clock'},
             'cpu_baseline': cpu,

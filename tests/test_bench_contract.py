@@ -43,4 +43,5 @@ def test_bench_line_contract():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert d['value'] > 0 and abs(d['value'] - 4096 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    assert 'power' in r and (r['power'] is None or (len(r['power']['sclk_mhz']) >= 1 and min(r['power']['package_watts']) > 0))
     assert d['replay']['estimator_only']['achieved'] > 0
