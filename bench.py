@@ -618,13 +618,6 @@ def main():
                         'fp64_flops': (fl / (avg_ms * 1e-3)) if fl else None, 'fp64_peak_flops': FP64_VECTOR_PEAK_FLOPS,
                         'fp64_frac': (fl / (avg_ms * 1e-3) / FP64_VECTOR_PEAK_FLOPS) if fl else None,
                         'source': 'instruction counts per launch from the committed PMC passes (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64), divided by this run\'s kernel time'}
-        power = None
-        if world == 1 and not args.no_power:
-            power = power_under_load(torch, launch, torch.cuda.current_device())
-        if power and valu:                                         # the issue peak at the clock the part actually sustains under this kernel
-            clk = float(np.mean(power['sclk_mhz'])) * 1e6
-            valu['sustained_clock_hz'] = clk
-            valu['frac_at_sustained_clock'] = valu['wave_instr_per_s'] / (1024 * clk / 4)
         side_ok = world == 1 and headline_shape and not args.no_side
         replay = None
         if world == 1 and args.config == 2 and not args.no_replay and not args.e2e and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
@@ -660,6 +653,13 @@ def main():
                                'failed_trials': int((status != 0).sum().item())}
                 noise = noise_head
             fp = fp_head
+        power = None
+        if world == 1 and not args.no_power:                       # after the short side measurements above (seconds of sustained load change what follows)
+            power = power_under_load(torch, launch, torch.cuda.current_device())
+        if power and valu:                                         # the issue peak at the clock the part actually sustains under this kernel
+            clk = float(np.mean(power['sclk_mhz'])) * 1e6
+            valu['sustained_clock_hz'] = clk
+            valu['frac_at_sustained_clock'] = valu['wave_instr_per_s'] / (1024 * clk / 4)
         side = {}
         if side_ok:
             for key in list(bufs):
