@@ -186,7 +186,8 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
                                   ('estimator_only_records', False, 8 * (2 * M + N + M * N), 'ktc')):
         if lay == 'ktc':                                          # the same streams as per-trial records ([step][trial][component]); same buffers
             f, dq = f.permute(0, 2, 1).contiguous(), dq.permute(0, 2, 1).contiguous()
-            x_buf, err_buf = x_buf.view(K, T, M * N), err_buf.view(K, T, M)
+            dense = lambda t, c: (t._base if t._base is not None else t).reshape(-1)[:K * T * c].view(K, T, c)   # noqa: E731 -- (pitched rows: the allocation behind the view)
+            x_buf, err_buf = dense(x_buf, M * N), dense(err_buf, M)
         ms = []
         for _ in range(reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -590,6 +590,9 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     {
         const long long nw = gridDim.x, nfull = (nw / 8) * 8;
         if (A.fp.reserved == 1 && chunk < nfull) chunk = (chunk % 8) * (nfull / 8) + chunk / 8;      // XCD x owns a contiguous eighth of the trials
+        if (A.fp.reserved >= 8 && A.fp.reserved < 16 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (A.fp.reserved - 8)) & 7);   // XCD x writes the 256-byte slot x + r of every 2 KB
+        if (A.fp.reserved >= 16 && A.fp.reserved < 24 && chunk < nfull) chunk = chunk ^ (A.fp.reserved - 16);                             // ... slot x ^ r
+        if (A.fp.reserved == 2 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (chunk >> 3)) & 7);                                    // ... every slot in turn
     }
     const long long wave_first = chunk * TPW;
 #else

@@ -9,6 +9,7 @@ wavefront load/store of a stream component is one contiguous 512-byte segment.  
 reference's per-trial record order.  The kernels take strides, so all three work everywhere.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -63,8 +64,16 @@ _DIMS = {'kct': (2, 0, 1), 'ktc': (1, 0, 2), 'tkc': (0, 1, 2)}
 
 
 def alloc_stream(T, K, comp, layout='kct', device='cuda', zero=False):
-    """fp64 tensor for a [trial][step][comp] stream in the requested physical layout."""
+    """fp64 tensor for a [trial][step][comp] stream in the requested physical layout.
+
+    Experiment knob UVS_ROW_PAD=<trials>: pitch trial-fastest rows at T + pad (the [:, :, :T] view is returned; every entry point takes
+    strides).  With dense rows of a power-of-two T every (step, component) row starts in the same 256-byte slot of the address interleave
+    and two of the eight slots drain 17 % slower on MI355X; walking the slots from row to row measured -1 % (config 3), -2 % (IMCC-KF),
+    +/-0 (headline) and +8 % (replay) on one box -- DESIGN.md appendix A.1 -- so dense rows stay the default."""
     torch = _torch()
+    pad = int(os.environ.get('UVS_ROW_PAD', '0'))
+    if layout == 'kct' and pad:
+        return (torch.zeros if zero else torch.empty)((K, comp, T + pad), dtype=torch.float64, device=device)[:, :, :T]
     shape = {'kct': (K, comp, T), 'ktc': (K, T, comp), 'tkc': (T, K, comp)}[layout]
     return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float64, device=device)
 
