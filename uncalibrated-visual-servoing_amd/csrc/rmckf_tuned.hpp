@@ -535,6 +535,9 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 #ifndef UVS_INC_SINCOS                  // experiment builds: 0 = sincos of every joint angle from scratch every step (round-2 code)
 #define UVS_INC_SINCOS 1
 #endif
+#ifndef UVS_FAIR_PRIO                   // log2 of the priority turn in shader clocks for the two-wavefront-per-SIMD kernels; experiment builds: 0 = off
+#define UVS_FAIR_PRIO 18
+#endif
 #ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 #define UVS_SHARED_OCC 2
 #endif
@@ -717,9 +720,25 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
 #endif
 
+    // Two wavefronts per SIMD (KF, IMCC-KF): left alone, issue arbitration serves the older wavefront first -- it finishes its 299 steps in
+    // 1.7 ms, the younger one in 2.4-2.8 ms, and runs the last third of its trial without a partner to hide its latencies behind.  The two
+    // take turns at the higher priority instead, by the shader clock (a turn = 2^18 cycles = 125 us), told apart by the parity of their
+    // wave slot; with equal parities both follow the same schedule and nothing changes.  Measured: residency 0.77 -> 0.86, KF 2.49 -> 2.43 ms.
+    unsigned fair_slot = 0;
+    constexpr bool FAIR = SHARED_P && L == 2 && UVS_FAIR_PRIO > 0;
+    if constexpr (FAIR) {
+        unsigned hw_id_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id_));
+        fair_slot = hw_id_ & 1u;                                 // WAVE_ID bit 0
+    }
     for (int k = 0; k < K; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         UVS_STAMP(5);
+        if constexpr (FAIR) {
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+            if ((((unsigned)(now_ >> (UVS_FAIR_PRIO > 0 ? UVS_FAIR_PRIO : 1))) ^ fair_slot) & 1u) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // ---- measurement noise: this step's values were requested a whole step ago; request the next step's now.  vmcnt counts in
         // order, so waiting for a load also waits for every older store: fetched at the top of the step that uses them, the loads sit
         // behind the previous step's err / q stores and the wait in front of the row updates inherits their write latency.
