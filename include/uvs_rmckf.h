@@ -200,6 +200,13 @@ int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void 
 int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream);
 
 /*
+ * Which instantiation uvs_noise_generate_f64 launches for these parameters (host-side query, no GPU work): 0 = the kernel of np->type,
+ * 1 = the alpha-stable kernel specialised for beta = 0 (noise.py:188-191), which evaluates cos((1 - alpha) V) by the addition theorem;
+ * it is selected only where that costs < 2e-14 relative (alpha from about 0.1 to 1.999, not 1 or 2).  <0 on bad arguments.
+ */
+int uvs_noise_kernel_variant(const uvs_noise_params *np);
+
+/*
  * Test hook: evaluates the library's fp64 helper functions on the device so that tests can bound their error against
  * numpy.  which: 0 fast reciprocal, 1 sqrt, 2 rsqrt, 3 sin, 4 cos (bounded-argument sincos with library fallback), 5 exp,
  * 6 exp for non-positive arguments, 7 log (own routine on normal positive arguments, library elsewhere), 8 exp with clamped argument.

@@ -278,3 +278,29 @@ def test_default_kernels_have_no_scratch():
     for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true>',
                  'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
         assert k[name]['scratch'] == 0, (name, k[name])
+
+
+def test_noise_kernel_variant_gate(uvs):
+    """Which alpha-stable parameters take the beta = 0 instantiation (cos((1 - alpha) V) by the addition theorem): the launcher's error bound
+    |(1 - alpha) / alpha| * 2e-16 / cos(|1 - alpha| pi / 2) <= 2e-14, never the reference's special cases (noise.py:180-185)."""
+    import ctypes as C
+    nd, NT = uvs.noise_device, uvs.NoiseType
+
+    def variant(kind, **p):
+        q = nd.make_noise_params(kind, p, 8, 10)
+        return uvs.lib().uvs_noise_kernel_variant(C.byref(q))
+
+    S = dict(beta=0.0, gamma=1.0, delta=0.0)
+    for alpha in (0.3, 0.5, 0.75, 1.0909090909090908, 1.5, 1.9090909090909092, 1.99):
+        assert variant(NT.ALPHA_STABLE, alpha=alpha, **S) == 1, alpha
+    for alpha in (0.05, 1.0, 2.0, 1.9999):                                  # error bound / Cauchy / Gaussian special cases
+        assert variant(NT.ALPHA_STABLE, alpha=alpha, **S) == 0, alpha
+    assert variant(NT.ALPHA_STABLE, alpha=1.5, beta=0.5, gamma=1.0, delta=0.0) == 0
+    assert variant(NT.ALPHA_STABLE, alpha=0.5, beta=1.0, gamma=1.0, delta=0.0) == 0
+    assert variant(NT.WHITE_NOISE, std=1.0) == 0 and variant(NT.GAUSSIAN_MIXTURE, std=1.0, mean=50.0, rho=0.1) == 0
+    # the bound itself, on both sides of its two edges
+    lo = [a for a in np.linspace(0.05, 0.3, 251) if variant(NT.ALPHA_STABLE, alpha=float(a), **S) == 1][0]
+    hi = [a for a in np.linspace(1.99, 2.0, 1001)[:-1] if variant(NT.ALPHA_STABLE, alpha=float(a), **S) == 1][-1]
+    for a in (lo, hi):
+        assert abs((1 - a) / a) * 2e-16 <= 2e-14 * np.cos(abs(1 - a) * np.pi / 2)
+    assert 0.05 < lo < 0.2 and 1.995 < hi < 2.0

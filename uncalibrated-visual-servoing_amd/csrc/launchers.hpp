@@ -57,6 +57,7 @@ bool replay_rows(int m, int n, int method, bool bywave, bool xo, bool eo, int64_
 void stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *stats, hipStream_t s);
 void debug_math(int which, long long n, const double *x, double *y, hipStream_t s);
 void noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s);
+int noise_variant(const uvs_noise_params &np);                       // 0 = kernel of np.type, 1 = beta = 0 alpha-stable specialisation
 void pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s);
 
 }  // namespace uvs_launch

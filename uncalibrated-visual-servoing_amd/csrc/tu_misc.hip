@@ -29,13 +29,17 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
         case UVS_NOISE_GAUSSIAN_MIXTURE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_MIXTURE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_GAUSSIAN_BIMODAL: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_BIMODAL>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_ALPHA_STABLE:
-            if (uvs::stable_symmetric_fast(np))
+            if (noise_variant(np) == 1)
                 hipLaunchKernelGGL(uvs::noise_kernel<uvs::kNoiseStableSymmetric>, g, dim3(64), 0, s, A);
             else
                 hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A);
             break;
         default: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_UNIFORM>, g, dim3(64), 0, s, A); break;
     }
+}
+
+int uvs_launch::noise_variant(const uvs_noise_params &np) {
+    return (np.type == UVS_NOISE_ALPHA_STABLE && uvs::stable_symmetric_fast(np)) ? 1 : 0;
 }
 
 void uvs_launch::pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s) {

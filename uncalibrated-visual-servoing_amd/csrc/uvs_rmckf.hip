@@ -192,6 +192,11 @@ int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t
     return check_launch("noise_kernel");
 }
 
+int uvs_noise_kernel_variant(const uvs_noise_params *np) {
+    if (!np || np->type < UVS_NOISE_WHITE || np->type > UVS_NOISE_UNIFORM) return fail(UVS_ERR_ARG, "%s", "bad noise parameters");
+    return noise_variant(*np);
+}
+
 int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void *stream) {
     if (n <= 0 || !seeds || !states) return fail(UVS_ERR_ARG, "%s", "bad pcg64_seed arguments");
     pcg64_seed((long long)n, (const unsigned long long *)seeds, (unsigned long long *)states, (hipStream_t)stream);
