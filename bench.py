@@ -282,12 +282,20 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4        # 256 CUs x 4 SIMDs, one wa
 FP64_VECTOR_PEAK_FLOPS = 78.6e12                     # MI355X_MICROARCH.md: fp64 vector peak
 
 
+def parse_rocm_smi(text):
+    """(package watts, shader clock in MHz, power cap in watts) from `rocm-smi --showpower --showclocks --showmaxpower` text; None where absent."""
+    import re
+    w = re.search(r'(?:Current Socket|Average) Graphics Package Power \(W\):\s*([\d.]+)', text)
+    c = re.search(r'sclk clock level:\s*\S+\s*\((\d+)Mhz\)', text)
+    m = re.search(r'Max Graphics Package Power \(W\):\s*([\d.]+)', text)
+    return (float(w.group(1)) if w else None, int(c.group(1)) if c else None, float(m.group(1)) if m else None)
+
+
 def power_under_load(torch, launch, device_index, max_seconds=10.0):
     """Package power and shader clock while the timed kernel runs back to back (side object, not part of the timed region): `rocm-smi`
     sampled up to three times from a thread, after 0.6 s of settling, while this thread keeps the launch queue full.  The closed-loop kernel
     is power-limited on MI355X: the clock it sustains, not the 2.4 GHz peak, is what its instruction rate sees.
     Returns None when rocm-smi is missing or prints nothing parseable."""
-    import re
     import shutil
     import subprocess
     import threading
@@ -304,13 +312,11 @@ def power_under_load(torch, launch, device_index, max_seconds=10.0):
                                      capture_output=True, text=True, timeout=20).stdout
             except Exception:                                      # noqa: BLE001 -- a missing / hanging tool must not cost the bench line
                 return
-            w = re.search(r'(?:Current Socket|Average) Graphics Package Power \(W\):\s*([\d.]+)', out)
-            c = re.search(r'sclk clock level:\s*\S+\s*\((\d+)Mhz\)', out)
-            m = re.search(r'Max Graphics Package Power \(W\):\s*([\d.]+)', out)
-            if m:
-                cap[0] = float(m.group(1))
-            if w and c:
-                samples.append((float(w.group(1)), int(c.group(1))))
+            watts, mhz, cap_w = parse_rocm_smi(out)
+            if cap_w is not None:
+                cap[0] = cap_w
+            if watts is not None and mhz is not None:
+                samples.append((watts, mhz))
 
     th = threading.Thread(target=sampler, daemon=True)
     th.start()

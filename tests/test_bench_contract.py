@@ -25,6 +25,23 @@ def test_cpu_baseline_runs_the_oracle_on_a_small_sample():
     assert out['value'] > 0 and 'oracle/rmckf_dense.py' in out['sample']
 
 
+def test_rocm_smi_text_is_parsed():
+    import bench
+    text = """
+============================ ROCm System Management Interface ============================
+GPU[0]		: fclk clock level: 0: (1250Mhz)
+GPU[0]		: mclk clock level: 0: (2000Mhz)
+GPU[0]		: sclk clock level: 1: (2131Mhz)
+======================================= Power Cap ========================================
+GPU[0]		: Max Graphics Package Power (W): 1400.0
+=================================== Power Consumption ====================================
+GPU[0]		: Current Socket Graphics Package Power (W): 1357.0
+"""
+    assert bench.parse_rocm_smi(text) == (1357.0, 2131, 1400.0)
+    assert bench.parse_rocm_smi('GPU[0] : sclk clock level: S: (95Mhz)\nGPU[0] : Average Graphics Package Power (W): 246.0') == (246.0, 95, None)
+    assert bench.parse_rocm_smi('no such tool') == (None, None, None)
+
+
 @pytest.mark.gpu
 def test_bench_line_contract():
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--trials', '4096', '--no-cpu-baseline']
