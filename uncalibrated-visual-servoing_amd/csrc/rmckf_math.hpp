@@ -154,7 +154,10 @@ UVS_DEV void sincos_bounded(double x, double &s, double &c) {
 // Rotation of a tracked (sin, cos) pair by a small angle d, |d| <= kSinCosStepMax: sin(t + d), cos(t + d) from the addition theorems
 // with Taylor polynomials in d (truncation < 3e-18 relative at the bound) -- 17 instructions against the 47 of sincos_bounded.  Each
 // application adds ~1 ulp of rounding to the pair, so callers re-seed it from the angle itself every kSinCosResync steps.
-constexpr double kSinCosStepMax = 0.1;
+#ifndef UVS_SINCOS_STEPMAX             // experiment builds: a huge value never re-seeds for a large step (timing only)
+#define UVS_SINCOS_STEPMAX 0.1
+#endif
+constexpr double kSinCosStepMax = UVS_SINCOS_STEPMAX;
 constexpr int kSinCosResync = 16;
 UVS_DEV void sincos_advance(double &s, double &c, double d) {
     const double z = d * d;
