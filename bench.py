@@ -348,7 +348,7 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
     NV = uvs_amd._lib.NULL_VIEW
     flat = lambda t: uvs_amd._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))     # noqa: E731
-    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev) for k, c in (('x', M * N), ('err', M), ('q', N))}
+    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev) for k, c in (('x', M * N), ('err', M), ('q', N), ('f', M))}
     noise = [engine.alloc_stream(T, K, M, 'kct', dev) for _ in range(2)]
     rows_dev = [torch.zeros((T, 5), dtype=torch.float64, device=dev) for _ in range(2)]
     rows_host = torch.empty((len(cells), T, 5), dtype=torch.float64).pin_memory()
@@ -363,10 +363,13 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
         params = dict(alpha=float(cells[c]), beta=0, gamma=1, delta=0)
         uvs_amd.noise_device.generate(nt, params, seeds_dev[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
 
-    def loop(c, buf, slot):
+    def loop(c, buf, slot, csv=False):
+        # csv: the per-step streams results.csv holds (main.py:152-194: error, q, f; the camera pose follows from q, the noise is the input) --
+        # the Jacobian estimate X, 384 of the headline's 560 B per update, is not among them
         rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
             C.byref(fp), C.byref(plant), T, flat(q0_all[c * T:(c + 1) * T]), engine.stream_view(buf, 'kct'), NV,
-            engine.stream_view(bufs['x'], 'kct'), engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'), NV, NV,
+            NV if csv else engine.stream_view(bufs['x'], 'kct'), engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'),
+            engine.stream_view(bufs['f'], 'kct') if csv else NV, NV,
             stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         uvs_amd._lib.check(rc)
         r = rows_dev[slot]
@@ -379,6 +382,12 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
         for c in range(len(cells)):
             gen(c, noise[0])
             loop(c, noise[0], 0)
+        torch.cuda.synchronize()
+
+    def serial_csv():
+        for c in range(len(cells)):
+            gen(c, noise[0])
+            loop(c, noise[0], 0, csv=True)
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream(device=dev)
@@ -399,7 +408,7 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
         torch.cuda.synchronize()
 
     out = {}
-    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped)):
+    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped), ('one_stream_csv_streams', serial_csv)):
         fn()                                                       # warm-up (allocator, tables)
         t0 = time.perf_counter()
         fn()
@@ -415,7 +424,8 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     out['breakdown_one_cell_ms'] = {'seeding_and_noise_generation': a.elapsed_time(b), 'closed_loop_kernel_and_row_copy': b.elapsed_time(c_)}
     out.update(workload=f'the reference sweep of main.py:104-148: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), X+err+q logged on the device, '
                         'per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory', cells=len(cells), trials_per_cell=T, updates_total=updates,
-               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell; never part of `value`')
+               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell; never part of `value`.  '
+                    'one_stream_csv_streams: the same sweep logging what results.csv holds per step (err, q, f: 176 B per update written) instead of X + err + q')
     del bufs, noise
     torch.cuda.empty_cache()
     return out
