@@ -775,3 +775,48 @@ def test_closed_loop_on_a_general_dh_table(uvs, method):
     a = uvs.engine.closed_loop(fp, ur10.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('err', 'q'))
     b = uvs.engine.closed_loop(fp, nearly.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('err', 'q'))
     assert rel_err(a['err'].cpu().numpy(), b['err'].cpu().numpy()) <= 1e-9 and rel_err(a['q'].cpu().numpy(), b['q'].cpu().numpy()) <= 1e-9
+
+
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF', 'MCKF'])
+def test_pitched_streams_give_the_same_bits(uvs, method, monkeypatch):
+    """Every entry point takes strides: input and output streams whose rows are pitched (UVS_ROW_PAD, engine.alloc_stream) -- an odd pad, so
+    that nothing is 16-byte aligned any more -- give bit-identical results to dense rows, closed loop and replay."""
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = 333
+    plan = uvs.batch.plan_trials(cfg, cells=[1.5])
+    K = 60
+    fp = uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0, steps=K, fpi_threshold=0.1, fpi_epoch_max=50)
+    plant = uvs.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    q0 = _cuda(plan.q_start)
+    want = ('x', 'err', 'q', 'f', 'dq')
+    res = {}
+    for pad in ('0', '37'):
+        monkeypatch.setenv('UVS_ROW_PAD', pad)
+        noise = uvs.batch.device_noise(cfg, plan, 0, len(plan), fp.steps, 'cuda')
+        assert noise.is_contiguous() == (pad == '0')
+        out = uvs.engine.closed_loop(fp, plant, q0, noise, want=want)
+        assert out['x'].is_contiguous() == (pad == '0')
+        rep = uvs.engine.replay(uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], False, 0, steps=K - 1,
+                                                       fpi_threshold=0.1, fpi_epoch_max=50),
+                                out['f'], out['dq'][:K - 1], out['x'][0].permute(1, 0).contiguous(), want=('x', 'err'))
+        res[pad] = {k: out[k].cpu().numpy() for k in want + ('stats', 'status', 'k_done')}
+        res[pad].update({'rx': rep['x'].cpu().numpy(), 'rerr': rep['err'].cpu().numpy(), 'rstatus': rep['status'].cpu().numpy()})
+    for k in res['0']:
+        assert np.array_equal(res['0'][k], res['37'][k], equal_nan=True), k
+
+
+def test_alloc_stream_row_pitch_knob(uvs, monkeypatch):
+    """UVS_ROW_PAD pitches the rows of trial-fastest streams; the caller sees the [K][comp][T] view either way."""
+    eng = uvs.engine
+    monkeypatch.delenv('UVS_ROW_PAD', raising=False)
+    dense = eng.alloc_stream(64, 5, 3, 'kct', 'cuda', zero=True)
+    assert dense.shape == (5, 3, 64) and dense.is_contiguous()
+    monkeypatch.setenv('UVS_ROW_PAD', '32')
+    pitched = eng.alloc_stream(64, 5, 3, 'kct', 'cuda', zero=True)
+    assert pitched.shape == (5, 3, 64) and pitched.stride() == (3 * 96, 96, 1) and not pitched.is_contiguous()
+    assert eng.as_tkc(pitched, 'kct').shape == (64, 5, 3)
+    v = eng.stream_view(pitched, 'kct')
+    assert (v.trial_stride, v.step_stride, v.comp_stride) == (1, 3 * 96, 96)
+    rec = eng.alloc_stream(64, 5, 3, 'ktc', 'cuda')                               # record layouts are never pitched
+    assert rec.is_contiguous() and rec.shape == (5, 64, 3)

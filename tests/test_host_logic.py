@@ -304,3 +304,4 @@ def test_noise_kernel_variant_gate(uvs):
     for a in (lo, hi):
         assert abs((1 - a) / a) * 2e-16 <= 2e-14 * np.cos(abs(1 - a) * np.pi / 2)
     assert 0.05 < lo < 0.2 and 1.995 < hi < 2.0
+
