@@ -11,9 +11,14 @@ one filter for one time step.
 
 Multi-GPU (one process per GPU under torch.distributed.run): trials are enumerated globally (main.py:121-139: seed0 + t, t-th jitter
 draw) and rank r owns the contiguous shard dist.shard_range(total, r, N) -- no data-path collective -- followed by one RCCL all-gather
-of the per-trial [ISE, IAE, ITAE, status] rows, which is inside the timed region.  --scaling strong (default: north_star's series, "a
-65 536-trial batch at 1, 2, 4 and 8 MI355X") keeps the TOTAL at the config's size, --scaling weak gives every GPU the config's size;
---config 4 is BASELINE config 4: 1 048 576 trials in total over however many ranks there are.
+of the per-trial [ISE, IAE, ITAE, status] rows, which is inside the timed region.  --scaling weak (default: per-GPU work fixed, the
+driver's scaling series) gives every GPU the config's size; --scaling strong keeps the TOTAL at the config's size (north_star's series, "a
+65 536-trial batch at 1, 2, 4 and 8 MI355X") -- a weak config-2 run on N > 1 ranks times that series too, right after the timed region, and
+reports it as the side object multi_gpu.strong_series; --config 4 is BASELINE config 4: 1 048 576 trials in total over however many ranks
+there are (always strong).
+
+Plain `python bench.py --gpus N` with N > 1 starts its own N ranks (fresh children under torch.distributed.run, before this process
+touches the GPU) and relays rank 0's line; under torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
 """
@@ -308,8 +313,9 @@ def power_under_load(torch, launch, device_index, max_seconds=10.0):
         time.sleep(0.6)
         for _ in range(3):
             try:
-                out = subprocess.run([exe, '-d', str(device_index), '--showpower', '--showclocks', '--showmaxpower'],
-                                     capture_output=True, text=True, timeout=20).stdout
+                # rocm-smi is a `#!/usr/bin/env python3` script: run it with this interpreter (no env hop) and without any injected profiler library
+                out = subprocess.run([sys.executable, os.path.realpath(exe), '-d', str(device_index), '--showpower', '--showclocks', '--showmaxpower'],
+                                     capture_output=True, text=True, timeout=20, env=scrubbed_env()).stdout
             except Exception:                                      # noqa: BLE001 -- a missing / hanging tool must not cost the bench line
                 return
             watts, mhz, cap_w = parse_rocm_smi(out)
@@ -431,6 +437,77 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     return out
 
 
+PROFILER_ENV_PREFIXES = ('ROCP', 'ROCTRACER', 'HSA_TOOLS', 'ROCTX')
+
+
+def under_profiler(env=None):
+    """True when a rocprofv3 / rocprofiler tool library is injected into this process (its children would inherit it)."""
+    env = os.environ if env is None else env
+    if any('rocprof' in env.get(k, '').lower() for k in ('LD_PRELOAD', 'HSA_TOOLS_LIB')):
+        return True
+    return any(k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_')) for k in env)
+
+
+def scrubbed_env(env=None):
+    """Environment for helper children (rocm-smi): no preloaded profiler library, no profiler variables -- a child that initialises the GPU
+    through an inherited tool library and then execs (a `#!/usr/bin/env` script does) is the hop this pool forbids."""
+    env = dict(os.environ if env is None else env)
+    for k in list(env):
+        if k == 'LD_PRELOAD' or k.startswith(PROFILER_ENV_PREFIXES):
+            env.pop(k)
+    return env
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks as FRESH children under
+    torch.distributed.run (the driver's own command shape) before this process has imported torch or touched the GPU, relay rank 0's one
+    JSON line on stdout, pass everything else to stderr and return the launcher's exit code.  A rendezvous port that was free when probed can
+    be taken before rank 0 binds it: that failure, and only that one, is retried on another port."""
+    import socket
+    import subprocess
+    import threading
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK', 'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')            # dmabuf IPC only on this pool (RCCL across processes)
+    rc = 1
+    for attempt in range(4):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors='replace')
+        tail, json_lines = [], []
+
+        def pump_err(pipe=proc.stderr, tail=tail):
+            for ln in pipe:
+                sys.stderr.write(ln)
+                tail.append(ln)
+                del tail[:-200]
+
+        th = threading.Thread(target=pump_err, daemon=True)
+        th.start()
+        for ln in proc.stdout:
+            if ln.startswith('{'):
+                json_lines.append(ln)
+            else:
+                sys.stderr.write(ln)
+        rc = proc.wait()
+        th.join(timeout=10)
+        if rc != 0 and not json_lines and attempt < 3 and any('ddress already in use' in ln or 'EADDRINUSE' in ln for ln in tail):
+            sys.stderr.write(f'bench.py: rendezvous port {port} was taken, retrying on another one\n')
+            continue
+        for ln in json_lines:
+            sys.stdout.write(ln)
+        sys.stdout.flush()
+        if rc == 0 and len(json_lines) != 1:
+            sys.stderr.write(f'bench.py: expected one JSON line from rank 0, got {len(json_lines)}\n')
+            return 1
+        return rc
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -439,7 +516,9 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5],
                     help='BASELINE.json config: 2 (headline, 65 536 trials), 3 (mixture + annealing, 262 144), 4 (config-2 inputs, 1 048 576 trials in total over all ranks), 5 (16-feature / 7-DoF stress)')
     ap.add_argument('--scaling', default=None, choices=['strong', 'weak'],
-                    help="strong (default): the config's trial count is the TOTAL, sharded over the ranks (north_star's 65 536-trial series); weak: every GPU runs the config's trial count")
+                    help="weak (default): every GPU runs the config's trial count, global trial numbering; strong: the config's trial count is the TOTAL, sharded over the "
+                         "ranks (north_star's 65 536-trial series; the default for --config 4, which names a total).  A weak config-2 run on N > 1 ranks also times "
+                         "the strong series as the side object multi_gpu.strong_series")
     ap.add_argument('--hold', action='store_true', help='config 3: hold outliers for 10 steps (noise.hold)')
     ap.add_argument('--trials', type=int, default=0, help="override the config's trial count (total for strong, per GPU for weak)")
     ap.add_argument('--lanes', type=int, default=0, help='lanes per filter (0 = library default)')
@@ -449,21 +528,28 @@ def main():
     ap.add_argument('--no-side', action='store_true', help='skip the side measurements of the default run (configs 3 / 3-hold / 5, other estimators, end-to-end sweep)')
     ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end sweep side object (counter passes: its 49 launches of the headline kernel on other noise would be averaged in)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend (gloo: ranks may share one GPU; testing only)')
+    ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'], help='torch.distributed backend (default: nccl = RCCL when every rank has a GPU of its own, gloo when ranks must share cards -- a 1-GPU box)')
+    ap.add_argument('--no-strong-series', action='store_true', help='N > 1, weak: skip the strong-series side measurement')
     ap.add_argument('--no-power', action='store_true', help='skip the power / clock samples under load (about 3 s of extra launches)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
     ap.add_argument('--host-noise', action='store_true', help='generate the noise streams with numpy on the host (default: HIP generator)')
     ap.add_argument('--layout', default=None, choices=['kct', 'ktc', 'tkc'], help='physical layout of the per-step streams (default: trial-fastest kct; config 5: per-trial records ktc)')
     args = ap.parse_args()
+    if under_profiler():                                          # rocprofv3 pass: no helper children from a GPU-initialised process, no 49 extra launches in the counters
+        args.no_power = args.no_e2e = True
 
     if args.layout is None:
         args.layout = 'ktc' if args.config == 5 else 'kct'    # 8 trials per wavefront at (32,7): only per-trial records give contiguous stores
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:         # plain `python bench.py --gpus N`: this process only starts the ranks
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: either run plain `python bench.py --gpus N` (it starts its own ranks) or '
+                 f'`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`')
     dist_on = world > 1 or args.force_dist
-    scaling = args.scaling or 'strong'
+    scaling = args.scaling or ('strong' if args.config == 4 else 'weak')   # config 4 names a total; every other config is a per-GPU size
     assert not (args.config == 4 and scaling == 'weak'), 'config 4 names a TOTAL (1 048 576 trials over all ranks): it has no weak form'
 
     import uvs_amd
@@ -499,7 +585,13 @@ def main():
         gen_s = time.perf_counter() - t0
 
     import torch
-    local_rank %= max(1, torch.cuda.device_count())              # gloo test mode: several ranks on one GPU
+    n_dev = max(1, torch.cuda.device_count())
+    backend_note = None
+    if args.backend is None:                                      # RCCL refuses two ranks on one card: ranks that must share cards gather over gloo
+        args.backend = 'nccl' if world <= n_dev else 'gloo'
+        if args.backend == 'gloo':
+            backend_note = f'{world} ranks on {n_dev} visible GPU(s): ranks share cards, the statistics gather runs over gloo (host) instead of RCCL -- a functional run, not a scaling measurement'
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
@@ -616,6 +708,63 @@ def main():
         total_updates, failed_total = updates_per_launch, failed_local
     value = total_updates * args.steps / wall
 
+    strong_side = None
+    if dist_on and world > 1 and scaling == 'weak' and args.config == 2 and not args.stats_only and not args.no_strong_series:
+        # north_star's series -- ONE 65 536-trial batch over the N ranks -- timed in the same job, with the same barriers and the same gather,
+        # right after the weak run (side object: never `value`).  Rank r owns dist.shard_range(65 536, r, N) of the global enumeration.
+        cfg_s = config2()
+        cfg_s['experiments']['epoch'] = args.trials or TRIALS_PER_GPU
+        plan_s = batch.plan_trials(cfg_s, cells=[ALPHA])
+        lo_s, hi_s = dist.shard_range(len(plan_s), rank, world)
+        Ts = hi_s - lo_s
+        noise_s = batch.device_noise(cfg_s, plan_s, lo_s, hi_s, K, dev)
+        q0_s = torch.as_tensor(plan_s.q_start[lo_s:hi_s].copy(), device=dev)
+        bufs_s = {k: engine.alloc_stream(Ts, K, c, 'kct', dev, zero=True) for k, c in (('x', M * N), ('err', M), ('q', N))}
+        stats_s = torch.zeros((Ts, 3), dtype=torch.float64, device=dev)
+        status_s = torch.zeros(Ts, dtype=torch.int32, device=dev)
+        k_done_s = torch.zeros(Ts, dtype=torch.int32, device=dev)
+        fp_s = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+
+        def launch_s():
+            rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
+                C.byref(fp_s), C.byref(plant), Ts, flat(q0_s), engine.stream_view(noise_s, 'kct'), NV, engine.stream_view(bufs_s['x'], 'kct'),
+                engine.stream_view(bufs_s['err'], 'kct'), engine.stream_view(bufs_s['q'], 'kct'), NV, NV, stats_s.data_ptr(), status_s.data_ptr(),
+                k_done_s.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            uvs_amd._lib.check(rc)
+
+        def gather_s():
+            rows = dist.pack_rows(stats_s, status_s)
+            return dist.gather_trial_rows(rows if args.backend == 'nccl' else rows.cpu(), len(plan_s))
+
+        for _ in range(max(1, args.warmup)):
+            launch_s()
+            gather_s()
+        barrier()
+        ev_s = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch_s()
+            e1.record()
+            gathered_s = gather_s()
+            ev_s.append((e0, e1))
+        barrier()
+        wall_s = time.perf_counter() - t0
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_s]))
+        w = torch.tensor([wall_s, k_ms, -k_ms], dtype=torch.float64, device=red_dev)
+        td.all_reduce(w, op=td.ReduceOp.MAX)
+        u = torch.tensor([int(k_done_s.sum().item()), int((status_s != 0).sum().item())], dtype=torch.int64, device=red_dev)
+        td.all_reduce(u)
+        assert gathered_s.shape == (len(plan_s), 4)
+        strong_side = {'scaling': 'strong', 'trials_total': len(plan_s), 'trials_rank0': Ts, 'n_gpus': world, 'steps': args.steps,
+                       'ms_per_step': float(w[0]) / args.steps * 1e3, 'value': int(u[0]) * args.steps / float(w[0]), 'unit': 'updates/s',
+                       'kernel_ms_avg_over_ranks': {'max': float(w[1]), 'min': -float(w[2])}, 'failed_trials': int(u[1]),
+                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0],
+                       'note': "north_star's series (one 65 536-trial batch sharded over the ranks + the same all-gather), timed with the same barriers right after the weak "
+                               'run of this job; a side object, never `value`.  A trial is a 299-step serial chain: shards below one round of wavefronts leave SIMDs idle'}
+        del bufs_s, noise_s
+
     if rank == 0:
         b_alg = 8 * (2 * M + N + M * N)                           # 560 B / update at (8,6): noise in, err + X + q out
         if args.stats_only:
@@ -709,8 +858,9 @@ def main():
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch,
                          'binds': 'HBM is the roofline BASELINE.json prescribes; the counters say the kernel is bound by VALU issue at one wavefront per SIMD (see `valu`), at the clock the package power cap leaves it (see `power`)',
                          'valu': valu, 'power': power},
-            'multi_gpu': {'kernel_ms_avg_over_ranks': rank_ms, 'gather_ms': gather_avg, 'gather_inside_timed_region': bool(dist_on), 'backend': args.backend if dist_on else None,
-                          'gather_note': 'all_gather of per-trial [ISE, IAE, ITAE, status] rows (32 B/trial); nccl: HIP events on the launch stream, gloo: host clock'},
+            'multi_gpu': {'kernel_ms_avg_over_ranks': rank_ms, 'gather_ms': gather_avg, 'gather_inside_timed_region': bool(dist_on), 'backend': args.backend if dist_on else None, 'backend_note': backend_note,
+                          'gather_note': 'all_gather of per-trial [ISE, IAE, ITAE, status] rows (32 B/trial); nccl: HIP events on the launch stream, gloo: host clock',
+                          'strong_series': strong_side},
             'cpu_baseline': cpu,
             'replay': replay,
             'config3': side.get('config3'), 'config3_hold': side.get('config3_hold'), 'config5': side.get('config5'), 'other_estimators': others, 'e2e': side.get('e2e'),

@@ -42,6 +42,35 @@ GPU[0]		: Current Socket Graphics Package Power (W): 1357.0
     assert bench.parse_rocm_smi('no such tool') == (None, None, None)
 
 
+def test_profiler_environment_is_detected_and_scrubbed():
+    """helper children (rocm-smi) must not inherit an injected profiler library; power / e2e are skipped under a profiler."""
+    import bench
+    plain = {'PATH': '/usr/bin', 'HOME': '/root'}
+    assert not bench.under_profiler(plain) and bench.scrubbed_env(plain) == plain
+    prof = dict(plain, LD_PRELOAD='/opt/rocm/lib/librocprofiler-sdk-tool.so', ROCPROFILER_LIBRARY_CTOR='1', ROCPROF_OUTPUT_PATH='/tmp/x',
+                HSA_TOOLS_LIB='/opt/rocm/lib/librocprofiler64.so', ROCP_TOOL_LIB='x')
+    assert bench.under_profiler(prof) and bench.under_profiler({'ROCPROF_COUNTERS': 'pmc: SQ_WAVES'})
+    assert bench.under_profiler({'LD_PRELOAD': '/x/librocprofiler-sdk-tool.so.1'}) and not bench.under_profiler({'LD_PRELOAD': '/x/libjemalloc.so'})
+    assert bench.scrubbed_env(prof) == plain
+
+
+def test_plain_gpus_n_starts_its_own_ranks_and_a_failing_rank_is_loud(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE must not assert: the parent starts two fresh ranks under torch.distributed.run.
+    On a box without a GPU every rank fails (no CPU fallback) -- the parent relays the failure as a non-zero exit code and prints no JSON.
+    A WORLD_SIZE that contradicts --gpus is refused with the two valid invocations spelled out."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''         # also on a GPU box: this test is about the failing path
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--trials', '64', '--no-cpu-baseline',
+                          '--no-side'], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert 'AssertionError' not in res.stderr.split('Traceback')[0]          # the parent itself did not trip over WORLD_SIZE
+    assert 'torch.distributed' in res.stderr or 'ChildFailedError' in res.stderr or 'no GPU' in res.stderr or 'HIP' in res.stderr
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                         env=dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0'))
+    assert res.returncode != 0 and 'WORLD_SIZE=3' in res.stderr and 'torch.distributed.run' in res.stderr
+
+
 @pytest.mark.gpu
 def test_bench_line_contract():
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--trials', '4096', '--no-cpu-baseline']
@@ -53,7 +82,7 @@ def test_bench_line_contract():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
                 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in d, key
-    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'strong'
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak'
     assert d['config']['trials_total'] == 4096 and d['config']['ranks_seen'] == 1 and d['multi_gpu']['gather_inside_timed_region'] is False
     assert d['vs_baseline'] is None and d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['unit'] == 'updates/s'
     assert 'workload' in d['config'] and 'model' not in d['config']

@@ -107,7 +107,7 @@ def test_one_rank_rccl_gather_equals_plain_run(tmp_path):
 def test_bench_force_dist_under_torchrun():
     """bench.py's multi-rank branch (process group, barrier, gather inside the timed region, max-over-ranks) on RCCL with one rank."""
     d = _torchrun_bench(1, '--force-dist', '--trials', '4096')
-    assert d['n_gpus'] == 1 and d['scaling'] == 'strong' and d['config']['trials_total'] == 4096 and d['config']['failed_trials'] == 0
+    assert d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['config']['trials_total'] == 4096 and d['config']['failed_trials'] == 0
     assert d['config']['ranks_seen'] == 1 and d['multi_gpu']['gather_inside_timed_region'] is True and d['multi_gpu']['backend'] == 'nccl'
     assert d['multi_gpu']['gather_ms'] >= 0 and d['multi_gpu']['kernel_ms_avg_over_ranks']['max'] >= d['multi_gpu']['kernel_ms_avg_over_ranks']['min'] > 0
     assert d['value'] > 0 and abs(d['value'] - 4096 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
@@ -130,11 +130,55 @@ def test_bench_two_ranks_by_name(scaling):
 def test_bench_three_ranks_strong_series():
     """Three gloo ranks sharing the GPU (the box allows six processes on the card: three ranks + the launcher + this test process leave a
     margin): north_star's strong series at a total the card holds three times over, ragged shards (4 099 = 1 367 + 1 366 + 1 366)."""
-    d = _torchrun_bench(3, '--backend', 'gloo', '--trials', '4099')
+    d = _torchrun_bench(3, '--backend', 'gloo', '--trials', '4099', '--scaling', 'strong')
     assert d['n_gpus'] == 3 and d['scaling'] == 'strong' and d['config']['trials_total'] == 4099 and d['config']['ranks_seen'] == 3
     assert d['config']['trials_rank0'] == 1367 and d['config']['failed_trials'] == 0
     assert abs(d['value'] - 4099 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     assert d['multi_gpu']['kernel_ms_avg_over_ranks']['max'] >= d['multi_gpu']['kernel_ms_avg_over_ranks']['min'] > 0
+
+
+def _plain_bench(*bench_args, expect_rc0=True):
+    """`python bench.py ...` exactly as the driver types it (no torchrun, no WORLD_SIZE): for --gpus N > 1 the process starts its own ranks."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + list(bench_args)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT, env=_env())
+    if not expect_rc0:
+        return res
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and res.stdout.strip() == lines[0]                 # one JSON line and nothing else on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """the driver's command shape with --gpus 2 on a 1-GPU box.  The parent starts two fresh ranks before touching the GPU;
+    with one visible card the ranks share it and the gather falls back to gloo (said so in the line).  Default series: weak (per-GPU work
+    fixed); north_star's strong series of the same job rides along as multi_gpu.strong_series."""
+    d = _plain_bench('--gpus', '2', '--steps', '2', '--warmup', '1', '--no-side', '--no-cpu-baseline', '--trials', '4096')
+    assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['scaling'] == 'weak' and d['config']['trials_total'] == 8192
+    assert d['config']['trials_rank0'] == 4096 and d['config']['failed_trials'] == 0
+    assert d['multi_gpu']['gather_ms'] > 0 and d['multi_gpu']['gather_inside_timed_region'] is True
+    assert d['multi_gpu']['backend'] == 'gloo' and 'share' in d['multi_gpu']['backend_note']
+    assert abs(d['value'] - 8192 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    s = d['multi_gpu']['strong_series']
+    assert s['scaling'] == 'strong' and s['trials_total'] == 4096 and s['trials_rank0'] == 2048 and s['n_gpus'] == 2 and s['failed_trials'] == 0
+    assert abs(s['value'] - 4096 * 299 / (s['ms_per_step'] * 1e-3)) / s['value'] < 1e-6
+
+
+@pytest.mark.timeout(900)
+def test_plain_bench_config_4_gpus_2():
+    d = _plain_bench('--config', '4', '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-side', '--no-cpu-baseline', '--trials', '8192')
+    assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['scaling'] == 'strong' and d['config']['trials_total'] == 8192
+    assert d['config']['trials_rank0'] == 4096 and 'config 4' in d['config']['workload'] and d['multi_gpu']['gather_ms'] > 0
+    assert d['multi_gpu']['strong_series'] is None
+
+
+@pytest.mark.timeout(900)
+def test_plain_bench_relays_a_failing_rank():
+    """A rank that dies (here: every rank, on an impossible request) makes the self-launching parent exit non-zero without a JSON line."""
+    res = _plain_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--no-side', '--no-cpu-baseline', '--trials', '1', expect_rc0=False)   # fewer trials than ranks
+    assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert 'fewer trials than ranks' in res.stderr
 
 
 @pytest.mark.timeout(900)

@@ -9,7 +9,14 @@ for what in "closed loop RMCKF:time_methods.py --methods GMCKF --reps 12000" "cl
   name=${what%%:*}; cmd=${what#*:}
   python3 tools/$cmd > /dev/null 2>&1 &
   pid=$!
-  while [ ! -s gpurun_out/.probe_started ]; do sleep 1; done; sleep 6
+  ok=0                                   # bounded wait for the tool's start marker: a tool that dies or never writes it must not hang the lease
+  for _ in $(seq 1 90); do
+    if [ -s gpurun_out/.probe_started ]; then ok=1; break; fi
+    if ! kill -0 $pid 2>/dev/null; then break; fi
+    sleep 1
+  done
+  if [ $ok -ne 1 ]; then echo "== $name: tools/$cmd did not start (exited or wrote no marker within 90 s); skipped"; kill $pid 2>/dev/null; wait $pid 2>/dev/null; continue; fi
+  sleep 6
   echo "== under load: $name"
   for i in 1 2 3; do rocm-smi --showpower --showclocks 2>&1 | grep -E "Power|sclk" | head -3; sleep 0.7; done
   kill $pid; wait $pid 2>/dev/null; rm -f gpurun_out/.probe_started

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run BASELINE config 2 once on the -DUVS_STAMPS build and print the per-phase cycle shares of the tuned kernel.
-usage (GPU box): UVS_LIB_PATH=<pkg>/libuvs_stamps.so python tools/read_stamps.py [lanes]"""
+usage (GPU box): UVS_LIB_PATH=tools/diag/libuvs_stamps.so python tools/read_stamps.py [lanes]"""
 import os
 import sys
 

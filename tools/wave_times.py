@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where the launch time of a closed-loop kernel goes, wavefront by wavefront (diagnostic build -DUVS_WAVE_TIMES):
 start / end wall time (100 MHz), XCD, CU and SIMD of every wavefront of one BASELINE config-2 launch per estimator.
-usage (GPU box): make -C uncalibrated-visual-servoing_amd/csrc quick QDEF=-DUVS_WAVE_TIMES QOUT=../libuvs_wt.so
-                 UVS_LIB_PATH=uncalibrated-visual-servoing_amd/libuvs_wt.so python tools/wave_times.py [--methods ...] [--alpha A]"""
+usage (GPU box): make -C uncalibrated-visual-servoing_amd/csrc quick QDEF=-DUVS_WAVE_TIMES QOUT=../../tools/diag/libuvs_wt.so
+                 UVS_LIB_PATH=tools/diag/libuvs_wt.so python tools/wave_times.py [--methods ...] [--alpha A]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -130,6 +130,7 @@ constexpr double kExpZeroBelow = -745.1332191019512, kExpNonzeroAbove = -745.133
 // fpi_default_*).  The kernels reproduce it by poisoning the gain of the row.
 constexpr double kRcpOverflowsAtOrBelow = 0x1p-1024;
 constexpr double kRcpOverflowArg = -709.78271289338397;          // ln(2^-1024): the same boundary on the argument of the exponential
+constexpr double kExpArgBand = 1e-11;                            // |argument - boundary| within which the tuned kernels hand the verdict to the careful pass
 UVS_DEV double mckf_poison(double gain, double cy) { return (cy <= kRcpOverflowsAtOrBelow) ? __builtin_nan("") : gain; }
 
 // Pre-pass of an MCKF step over the lane's rows: innovation of every row against the prior state, to find out whether some Cy is
@@ -144,6 +145,7 @@ UVS_DEV void mckf_underflow_prepass(FpiProbe &fpi, ArgOfRow arg_of_row) {
         zero |= a < kExpZeroBelow;
         unsure |= (a >= kExpZeroBelow) && (a <= kExpNonzeroAbove);    // (a NaN argument is not "unsure": that trial FAILs by itself, no second pass)
         poison |= a < kRcpOverflowArg;                                // decided on the argument: no weight has to stay live for it
+        unsure |= fabs(a - kRcpOverflowArg) <= kExpArgBand;           // ... and within rounding of that boundary only the careful pass (which decides on the weight) may say
     }
     fpi.skip = zero;
     fpi.unsure = unsure;
@@ -442,7 +444,7 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 // the treatment of row m is selected per lane.
 // Returns true when the |R_cc| spread marks the Jacobian as numerically rank-deficient (rmckf_device.hpp, "numpy.linalg.pinv
 // semantics"): the caller flags the trial and the careful second pass redoes it; the solution computed here is then discarded.
-// nonfinite: some entry of the panel's Jacobian part is NaN or infinite.  A non-finite entry of column j reaches, through the reflector
+// nonfinite: some entry of the panel's Jacobian part is NaN or infinite (decided on NaN norms; see the end of the function for +inf).  A non-finite entry of column j reaches, through the reflector
 // of an earlier column at the latest, every remaining row of column j, so the squared column norm n2 that column j's own step forms is
 // non-finite: the exponent watch sees it for free, and the closed-loop kernel needs no separate finiteness probe of X (24 instructions per step).
 template <int M, int N, int L>
@@ -494,8 +496,12 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     }
     // (a column that vanished exactly -- lo == 0 -- sends NaNs through the remaining columns by itself: that trial is marked for the careful
     // second pass, which probes X entry by entry, and is not FAILed here)
-    nonfinite = spread.hi >= 0x7ff00000u && spread.lo != 0u;
-    return spread.suspect();
+    // NaN (high dword above +inf's 0x7ff00000) proves a non-finite entry.  A norm of exactly +inf does not: a FINITE entry beyond ~1e154
+    // overflows the square, and numpy's SVD does not raise on that -- such a trial is marked for the careful pass (which probes X entry by
+    // entry) instead of FAILed here.  An infinite entry in any but the last column turns a later column's norm into NaN (0 * inf in the
+    // reflector); in the last column it goes the careful way too and FAILs there, at the same step.
+    nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
+    return spread.suspect() || spread.hi == 0x7ff00000u;
 }
 
 template <int M, int N, int L>
@@ -1102,7 +1108,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 asm volatile("" ::: "memory");
             }
         }
-        if (!__any(alive)) break;
         if constexpr (METHOD == UVS_METHOD_MCKF && XREG) {       // register-resident variants: first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
             fpi.den = pair_sum<L>(fpi.den);
@@ -1147,6 +1152,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
             for (int j = 0; j < N; ++j) dq[j] = -fp.gain * sol[j];
         }
+        if (!__any(alive)) break;                                // the last live trial of the wavefront just FAILed: nothing left to log
         UVS_STAMP(2);                                            // control law
 
         // ---- logs and statistics
