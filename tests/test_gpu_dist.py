@@ -176,7 +176,7 @@ def test_plain_bench_config_4_gpus_2():
 @pytest.mark.timeout(900)
 def test_plain_bench_relays_a_failing_rank():
     """A rank that dies (here: every rank, on an impossible request) makes the self-launching parent exit non-zero without a JSON line."""
-    res = _plain_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--no-side', '--no-cpu-baseline', '--trials', '1', expect_rc0=False)   # fewer trials than ranks
+    res = _plain_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--no-side', '--no-cpu-baseline', '--scaling', 'strong', '--trials', '1', expect_rc0=False)   # fewer trials than ranks
     assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
     assert 'fewer trials than ranks' in res.stderr
 
