@@ -261,10 +261,9 @@ def side_config(config, torch, uvs_amd, engine, batch, dev, trials=None, reps=5,
     for i in range(warm + reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, layout), NV if x0 is None else flat(x0),
+        rc = engine.launch_closed_loop(fp, plant, T, flat(q0), engine.stream_view(noise, layout), NV if x0 is None else flat(x0),
             engine.stream_view(bufs['x'], layout), engine.stream_view(bufs['err'], layout), engine.stream_view(bufs['q'], layout), NV, NV,
-            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev)
         uvs_amd._lib.check(rc)
         e1.record()
         torch.cuda.synchronize()
@@ -372,11 +371,10 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     def loop(c, buf, slot, csv=False):
         # csv: the per-step streams results.csv holds (main.py:152-194: error, q, f; the camera pose follows from q, the noise is the input) --
         # the Jacobian estimate X, 384 of the headline's 560 B per update, is not among them
-        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0_all[c * T:(c + 1) * T]), engine.stream_view(buf, 'kct'), NV,
+        rc = engine.launch_closed_loop(fp, plant, T, flat(q0_all[c * T:(c + 1) * T]), engine.stream_view(buf, 'kct'), NV,
             NV if csv else engine.stream_view(bufs['x'], 'kct'), engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'),
             engine.stream_view(bufs['f'], 'kct') if csv else NV, NV,
-            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev)
         uvs_amd._lib.check(rc)
         r = rows_dev[slot]
         r[:, :3] = stats
@@ -650,11 +648,10 @@ def main():
     NV = uvs_amd._lib.NULL_VIEW
 
     def launch():
-        rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-            C.byref(fp), C.byref(plant), T, flat(q0), engine.stream_view(noise, args.layout), NV if x0 is None else flat(x0),
+        rc = engine.launch_closed_loop(fp, plant, T, flat(q0), engine.stream_view(noise, args.layout), NV if x0 is None else flat(x0),
             NV if args.stats_only else engine.stream_view(bufs['x'], args.layout),
             NV if args.stats_only else engine.stream_view(bufs['err'], args.layout), NV if args.stats_only else engine.stream_view(bufs['q'], args.layout), NV, NV, stats.data_ptr(), status.data_ptr(),
-            k_done.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            k_done.data_ptr(), NV, NV, device=dev)
         uvs_amd._lib.check(rc)
 
     def gather():
@@ -726,10 +723,9 @@ def main():
         fp_s = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
 
         def launch_s():
-            rc = uvs_amd.lib().uvs_rmckf_closed_loop_f64(
-                C.byref(fp_s), C.byref(plant), Ts, flat(q0_s), engine.stream_view(noise_s, 'kct'), NV, engine.stream_view(bufs_s['x'], 'kct'),
+            rc = engine.launch_closed_loop(fp_s, plant, Ts, flat(q0_s), engine.stream_view(noise_s, 'kct'), NV, engine.stream_view(bufs_s['x'], 'kct'),
                 engine.stream_view(bufs_s['err'], 'kct'), engine.stream_view(bufs_s['q'], 'kct'), NV, NV, stats_s.data_ptr(), status_s.data_ptr(),
-                k_done_s.data_ptr(), NV, NV, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                k_done_s.data_ptr(), NV, NV, device=dev)
             uvs_amd._lib.check(rc)
 
         def gather_s():
@@ -816,7 +812,8 @@ def main():
                 avg = float(np.mean(ms))
                 others[key] = {'avg_kernel_ms': avg, 'updates_per_s': upd / (avg * 1e-3), 'achieved': upd * b_alg / (avg * 1e-3) / 1e9, 'unit': 'GB/s',
                                'frac': upd * b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches_timed': 5, 'alpha': alpha, 'updates_per_launch': upd,
-                               'failed_trials': int((status != 0).sum().item())}
+                               'failed_trials': int((status != 0).sum().item()),
+                               'work_items_per_trial': int(uvs_amd.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), T))}
                 noise = noise_head
             fp = fp_head
         power = None

@@ -26,6 +26,7 @@
 #ifndef UVS_RMCKF_H
 #define UVS_RMCKF_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,7 +74,8 @@ typedef struct uvs_filter_params {
     double reg;                 /* 0.001**2 added to Cy before inversion (:280)                     */
     double fpi_threshold;       /* MCKF fixed-point stop test (:38, :215)                           */
     int32_t fpi_epoch_max;      /* MCKF iteration cap; reaching it skips the correction (:39, :246) */
-    int32_t reserved;
+    int32_t reserved;           /* option bits, 0 = defaults.  bits 8-15: segments per MCKF trial for                   */
+                                /* uvs_rmckf_closed_loop_ws_f64 (0 = library's choice); all other bits must be 0          */
     double desired[UVS_MAX_M];  /* desired_f (:21)                                                  */
 } uvs_filter_params;
 
@@ -129,6 +131,25 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
                               uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
                               double *stats, int32_t *status, int32_t *k_done,
                               uvs_view x_final, uvs_view p_final, void *stream);
+
+/*
+ * The same call with a caller-owned scratch buffer (DEVICE memory, 8-byte aligned, contents irrelevant before and after the call; the
+ * library still allocates nothing).  With it the MCKF closed loop (Method.MCKF, experiment.py:194-250) may cut every trial into segments
+ * -- work items of a few dozen steps whose filter state crosses through the workspace -- so that a wavefront held up by trials whose
+ * fixed-point iteration keeps iterating does not serialise with the next wavefront of its SIMD.  Results are
+ * bit-identical to the call without a workspace.  uvs_rmckf_closed_loop_workspace_bytes() says how much this (fp, plant, T) wants: 0 when
+ * segments would not help (other estimators, launches of one round or of many rounds of wavefronts); a NULL or too small workspace simply
+ * runs unsegmented.  Bits 8-15 of fp->reserved, when non-zero, fix the number of segments (1 = never cut; testing / measurements).
+ * One workspace must not be shared by calls that may run concurrently on different streams.
+ */
+size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
+/* Segments per trial the call above would use given a large enough workspace (1 = whole trials); host-side query for logs and benchmarks. */
+int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
+int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T,
+                                 uvs_view q_start, uvs_view noise, uvs_view x0,
+                                 uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
+                                 double *stats, int32_t *status, int32_t *k_done,
+                                 uvs_view x_final, uvs_view p_final, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Open-loop replay of recorded streams through the estimator + control law

@@ -238,3 +238,94 @@ def test_infinite_sample_is_a_skipped_correction_for_mckf(uvs, lanes):
         assert np.array_equal(X[:, :, 0], X[:, :, 2]) and rel_err(X[:11, :, 1], X[:11, :, 0]) <= 1e-12
         if method == 'MCKF':
             assert np.all(np.isfinite(X[11, :, 1])) and rel_err(X[11, :, 1], X[10, :, 1]) <= 1e-15    # skipped correction: X unchanged
+
+
+# ---------------------------------------------------------------------------------------------- segmented trials (uvs_rmckf_closed_loop_ws_f64)
+def _seg_fp(uvs, base, segments):
+    fp = type(base).from_buffer_copy(base)
+    fp.reserved = segments << 8
+    return fp
+
+
+@pytest.mark.parametrize('segments', [2, 3, 8, 16])
+@pytest.mark.parametrize('name', FPI)
+def test_segmented_trials_equal_whole_trials_on_reference_fixtures(uvs, name, segments):
+    """A trial cut into work items whose state crosses HBM is the same arithmetic: status, k_done and every stream bit for
+    bit, on the reference's own MCKF runs that iterate, skip and FAIL -- and still within the fixture's gate."""
+    import torch
+    g = load_golden(name)
+    k = len(g['t'])
+    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    T = 70                                                                    # three wavefronts, the last one ragged
+    q0, nz = _cuda(np.tile(g['q_start'], (T, 1))), _cuda(np.repeat(g['noise_full'][:, :, None], T, axis=2))
+    base = _fp(uvs, g)
+    whole = uvs.engine.closed_loop(_seg_fp(uvs, base, 1), plant, q0, nz, want=('x', 'err', 'q', 'f', 'dq'), final_state=True)
+    assert uvs.engine.workspace(_seg_fp(uvs, base, 1), plant, T, 'cuda') == (None, 0)
+    fp = _seg_fp(uvs, base, segments)
+    ptr, nbytes = uvs.engine.workspace(fp, plant, T, 'cuda')
+    assert ptr is not None and nbytes >= 3 * 64 * 8 * 100
+    cut = uvs.engine.closed_loop(fp, plant, q0, nz, want=('x', 'err', 'q', 'f', 'dq'), final_state=True)
+    assert torch.equal(whole['status'], cut['status']) and torch.equal(whole['k_done'], cut['k_done'])
+    assert cut['status'].cpu().tolist() == [int(g['status'])] * T and cut['k_done'].cpu().tolist() == [k] * T
+    for key in ('x', 'err', 'q', 'f', 'dq'):
+        assert torch.equal(whole[key][:k].view(torch.int64), cut[key][:k].view(torch.int64)), key
+    assert torch.equal(whole['stats'].view(torch.int64), cut['stats'].view(torch.int64))
+    if int(g['status']) == 0:
+        for key in ('x_final', 'p_final'):
+            assert torch.equal(whole[key].view(torch.int64), cut[key].view(torch.int64)), key
+    assert rel_err(cut['err'].cpu().numpy()[:k, :, 0], g['err']) <= TOL.get(name, 1e-8)
+
+
+@pytest.mark.parametrize('thr,cap,segments', [(1e-3, 1000, 4), (1e-4, 3, 7), (0.1, 1000, 2)])
+def test_segmented_mixed_batch_is_bit_identical(uvs, thr, cap, segments):
+    """150 trials of mixed temper (iterating, skipping, FAILing at different steps -- also inside a segment and right at its edges):
+    the segmented launch reproduces the whole-trial launch bit for bit, rows at and after k_done excepted (unspecified)."""
+    import torch
+    import bench
+    desired = bench.config2()['experiments']['desired_f']
+    T, K = 150, 90
+    q0, noise = _mixed_batch(np.random.default_rng(77), T, K)
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    outs = []
+    for n in (1, segments):
+        fp = uvs.engine.make_params(8, 6, 'MCKF', 10.0, False, 0.05, 15.0, 0.2, desired, True, 0, K, thr, cap)
+        fp.reserved = n << 8
+        outs.append(uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q')))
+    a, b = outs
+    assert torch.equal(a['status'], b['status']) and torch.equal(a['k_done'], b['k_done']) and int((a['status'] == 1).sum()) >= (3 if cap > 1 else 0)
+    live = torch.arange(K, device='cuda')[:, None, None] < a['k_done'][None, None, :]
+    for key in ('x', 'err', 'q'):
+        assert torch.equal(torch.where(live, a[key], 0.0).view(torch.int64), torch.where(live, b[key], 0.0).view(torch.int64)), key
+    ok = a['status'] == 0
+    assert torch.equal(a['stats'][ok].view(torch.int64), b['stats'][ok].view(torch.int64))
+
+
+def test_workspace_too_small_or_absent_runs_whole_trials(uvs):
+    """The workspace is an offer: NULL or too small simply runs unsegmented (same bits); a misaligned pointer is an argument error."""
+    import ctypes as C
+    import torch
+    import bench
+    desired = bench.config2()['experiments']['desired_f']
+    T, K = 64, 40
+    q0, noise = _mixed_batch(np.random.default_rng(3), T, K)
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    fp = uvs.engine.make_params(8, 6, 'MCKF', 10.0, False, 0.05, 15.0, 0.2, desired, True, 0, K, 1e-3, 1000)
+    fp.reserved = 4 << 8
+    need = int(uvs.lib().uvs_rmckf_closed_loop_workspace_bytes(C.byref(fp), C.byref(plant), T))
+    assert need > 0
+    ref = uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('err',))
+    qd, nd = _cuda(q0), _cuda(noise.transpose(1, 2, 0))
+    NV = uvs._lib.NULL_VIEW
+    flat = lambda t: uvs._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))          # noqa: E731
+    buf = torch.zeros(need + 64, dtype=torch.uint8, device='cuda')
+    for ws, nbytes, want_rc in ((None, 0, 0), (buf.data_ptr(), need - 1, 0), (buf.data_ptr() + 4, need, -1), (buf.data_ptr() + 8, need, 0)):
+        err = uvs.engine.alloc_stream(T, K, 8)
+        stats, status, k_done = torch.zeros((T, 3), dtype=torch.float64, device='cuda'), torch.zeros(T, dtype=torch.int32, device='cuda'), torch.zeros(T, dtype=torch.int32, device='cuda')
+        rc = uvs.lib().uvs_rmckf_closed_loop_ws_f64(C.byref(fp), C.byref(plant), T, flat(qd), uvs.engine.stream_view(nd), NV, NV, uvs.engine.stream_view(err), NV, NV, NV,
+                                                    stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, ws, nbytes, None)
+        torch.cuda.synchronize()
+        assert rc == want_rc
+        if rc == 0:
+            assert torch.equal(k_done, ref['k_done']) and torch.equal(status, ref['status'])
+            live = torch.arange(K, device='cuda')[:, None, None] < k_done[None, None, :]
+            assert torch.equal(torch.where(live, err, 0.0).view(torch.int64), torch.where(live, ref['err'], 0.0).view(torch.int64))

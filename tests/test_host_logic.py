@@ -50,6 +50,32 @@ def test_argument_errors_are_reported_not_thrown(uvs):
     assert lib.uvs_supported_lanes(8, 6, None, 0) >= 4 and lib.uvs_supported_lanes(7, 7, None, 0) == 0
 
 
+def test_workspace_query_is_host_logic(uvs):
+    """uvs_rmckf_closed_loop_workspace_bytes: which launches the library would cut into segments (MCKF on the tuned two-lane kernel, DH plant,
+    more than one round of wavefronts) and how much caller-owned scratch that takes -- no GPU involved."""
+    lib = uvs.lib()
+    plant = uvs.SyntheticPlant.ur10().to_struct()
+    q = lambda fp, T: int(lib.uvs_rmckf_closed_loop_workspace_bytes(ctypes.byref(fp), ctypes.byref(plant), T))   # noqa: E731
+    per_chunk = (3 * 6 + 6 + 4 + 1 + 4 * 21 + 4 * 6 + 12 + 1) * 64 * 8
+    mckf = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8))
+    assert q(mckf, 32768) == 0                                             # one round of wavefronts: nothing to balance
+    seg = lambda fp, T: int(lib.uvs_rmckf_closed_loop_segments(ctypes.byref(fp), ctypes.byref(plant), T))      # noqa: E731
+    assert [seg(mckf, T) for T in (32768, 32769, 65536, 98304, 98305, 1048576)] == [1, 8, 8, 8, 4, 4]
+    assert q(mckf, 65536) == 2048 * 4 + 2048 * per_chunk                   # flags + state
+    assert q(mckf, 65537) == (2049 * 4 + 255) // 256 * 256 + 2049 * per_chunk
+    assert q(uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8)), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 65536) == 0
+    assert q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=4), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=-2), 65536) == 0
+    forced = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8)); forced.reserved = 3 << 8
+    assert q(forced, 40) == 256 + 2 * per_chunk
+    forced.reserved = 1 << 8
+    assert q(forced, 65536) == 0
+    short = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), steps=20); short.reserved = 4 << 8
+    assert q(short, 65536) == 0                                            # nothing to cut in a 20-step trial
+    linp = uvs._lib.Plant(); linp.kind = uvs._lib.PLANT_LINEAR; linp.n_joints = 6
+    assert int(lib.uvs_rmckf_closed_loop_workspace_bytes(ctypes.byref(mckf), ctypes.byref(linp), 65536)) == 0
+    assert int(lib.uvs_rmckf_closed_loop_workspace_bytes(None, ctypes.byref(plant), 65536)) == 0
+
+
 def test_missing_library_is_loud(uvs, monkeypatch):
     monkeypatch.setattr(uvs._lib, '_lib', None)
     monkeypatch.setattr(uvs._lib, 'LIB_PATH', '/nonexistent/libuvs_rmckf.so')

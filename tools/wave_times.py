@@ -18,6 +18,7 @@ ap.add_argument('--alpha', type=float, default=1.5)
 ap.add_argument('--lanes', type=int, default=0)
 ap.add_argument('--map', type=int, default=0, help='workgroup -> trial chunk mapping of the diagnostic build (fp.reserved)')
 ap.add_argument('--want', default='x,err,q')
+ap.add_argument('--segments', type=int, default=0, help='MCKF: work items per trial chunk (bits 8-15 of fp.reserved); every item is stamped')
 args = ap.parse_args()
 T, dev = args.trials, torch.device('cuda')
 cfg = bench.config2()
@@ -31,7 +32,9 @@ plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
 tpw = 64 // (args.lanes or 2)
 for meth in args.methods.split(','):
     fp = engine.make_params(8, 6, meth, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
-    fp.reserved = args.map
+    fp.reserved = (args.map << 16) | (args.segments << 8)
+    import ctypes as C
+    nseg = int(uvs_amd.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), T))
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -39,7 +42,18 @@ for meth in args.methods.split(','):
         e1.record(); torch.cuda.synchronize()
     st = out['stats'].cpu().numpy().ravel()
     nw = T // tpw
-    w = np.stack([st[3 * i * tpw: 3 * i * tpw + 4] for i in range(nw)])
+    w = np.stack([st[3 * i * tpw + 4 * sg: 3 * i * tpw + 4 * sg + 4] for sg in range(nseg) for i in range(nw)])
+    nw *= nseg
+    if nseg > 1:                                                   # per segment, and the chains of the chunks that end last
+        nchunk = nw // nseg
+        W = w.reshape(nseg, nchunk, 4)
+        base = W[:, :, 0].min()
+        S0, S1 = (W[:, :, 0] - base) / 100.0, (W[:, :, 1] - base) / 100.0
+        for sg in range(nseg):
+            d = S1[sg] - S0[sg]
+            print(f'   segment {sg}: starts p50 {np.median(S0[sg]):.0f} us, durations p10 {np.quantile(d, .1):.0f} p50 {np.median(d):.0f} p90 {np.quantile(d, .9):.0f} p99 {np.quantile(d, .99):.0f} max {d.max():.0f} us')
+        for c in np.argsort(S1[-1])[-4:]:
+            print(f'   chunk {c}: ' + '  '.join(f'[{S0[sg, c]:.0f} .. {S1[sg, c]:.0f}]' for sg in range(nseg)) + f'  busy {np.sum(S1[:, c] - S0[:, c]):.0f} us')
     w = w[np.argsort(w[:, 0])]
     t0, t1 = (w[:, 0] - w[:, 0].min()) / 100.0, (w[:, 1] - w[:, 0].min()) / 100.0          # microseconds
     hw, xcc = w[:, 2].astype(np.int64), w[:, 3].astype(np.int64) & 0xF
@@ -47,8 +61,8 @@ for meth in args.methods.split(','):
     dur = t1 - t0
     span = t1.max()
     print(f'== {meth}: event time {e0.elapsed_time(e1):.3f} ms; wavefronts {nw}; first start .. last end {span / 1e3:.3f} ms; residency (sum of durations / slots x span) '
-          f'{dur.sum() / (span * min(nw, 1024 * (2 if meth in ("KF", "IMCCKF") else 1))):.3f}')
-    print(f'   start times us: p0 {t0.min():.0f} p50 {np.median(t0):.0f} p90 {np.quantile(t0, .9):.0f} max {t0.max():.0f};  second-round starts (> 100 us): {(t0 > 100).sum()}')
+          f'{dur.sum() / (span * min(nw, 1024 * (2 if meth in ("KF", "IMCCKF") else 1))):.3f}; work items per chunk {nseg}')
+    print(f'   start times us: p0 {t0.min():.0f} p50 {np.median(t0):.0f} p90 {np.quantile(t0, .9):.0f} max {t0.max():.0f};  later-round starts (> 100 us): {(t0 > 100).sum()}')
     print(f'   durations  us: min {dur.min():.0f} p10 {np.quantile(dur, .1):.0f} p50 {np.median(dur):.0f} p90 {np.quantile(dur, .9):.0f} max {dur.max():.0f}')
     print(f'   end times  us: p10 {np.quantile(t1, .1):.0f} p50 {np.median(t1):.0f} p90 {np.quantile(t1, .9):.0f} p99 {np.quantile(t1, .99):.0f} max {t1.max():.0f}')
     for x in range(8):

@@ -98,6 +98,7 @@ struct View {
 static inline View to_view(const uvs_view &v) { return View{v.base, v.trial_stride, v.step_stride, v.comp_stride}; }
 
 // ---------------------------------------------------------------- kernel argument blocks (passed by value)
+constexpr int kMaxSegments = 16;
 struct ClosedArgs {
     uvs_filter_params fp;
     uvs_plant plant;
@@ -105,7 +106,20 @@ struct ClosedArgs {
     View q_start, noise, x0, x_out, err_out, q_out, f_out, dq_out, x_final, p_final;
     double *stats;
     int *status, *k_done;
+    // Segmented trials (tuned two-lane MCKF kernel, uvs_rmckf_closed_loop_ws_f64): n_seg > 1 cuts the K steps of a trial chunk into n_seg work
+    // items; the filter state crosses from one item to the next through ws_state, ws_flags[chunk] counts the chunk's finished segments.
+    double *ws_state = nullptr;
+    int *ws_flags = nullptr;
+    int n_seg = 1;
+    int seg_first[kMaxSegments + 1] = {};       // segment s covers steps [seg_first[s], seg_first[s + 1])
 };
+// Doubles per lane that one trial-chunk state occupies in the workspace (an upper bound over the kernel variants of a shape, so that the
+// C ABI can size the workspace without knowing which one runs): joints + their sines / cosines, command, previous features, clock,
+// covariance blocks, X, the twelve statistics accumulators, one word of flags.
+constexpr int seg_state_doubles(int M, int N, int L) {
+    return 3 * N + N + (M / L) + 1 + (M / L) * (N * (N + 1) / 2) + (M / L) * N + 3 * (M / L) + 1;
+}
+constexpr int kSegSpinMax = 1 << 22;            // x ~1 us of s_sleep: after ~4 s without its predecessor a segment recomputes the trial from step 0 instead
 
 struct ReplayArgs {
     uvs_filter_params fp;

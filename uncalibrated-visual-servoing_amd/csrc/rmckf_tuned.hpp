@@ -552,6 +552,10 @@ __global__ __launch_bounds__(64, (L >= 4 ? 2 : ((METHOD == UVS_METHOD_KF || METH
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
+    // MCKF trials differ in length (a trial that iterates costs its whole wavefront the fixed-point branch): with exactly two rounds of
+    // wavefronts a slow one serialises with its slot's second wavefront.  The two-lane MCKF kernel can therefore run a chunk's K steps as
+    // A.n_seg work items, the state crossing through HBM (uvs_rmckf_closed_loop_ws_f64); same arithmetic, bit-identical results.
+    constexpr bool SEG = (METHOD == UVS_METHOD_MCKF && L == 2 && !XREG && PLANT != UVS_PLANT_LINEAR);   // (the linear-plant instantiation has no registers to spare for it)
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool DH = (PLANT == UVS_PLANT_DH_PINHOLE || PLANT == kPlantDhAxisAligned);
@@ -589,30 +593,73 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         item_ = (unsigned)__builtin_amdgcn_readfirstlane((int)item_);
         if ((long long)item_ * TPW >= A.T) break;
         const long long wave_first = (long long)item_ * TPW;
+        const long long chunk = item_;
+        const int seg = 0;
 #ifdef UVS_WAVE_TIMES
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
 #endif
 #define UVS_ITEM_END continue
-#elif defined(UVS_WAVE_TIMES)           // experiment: workgroup -> trial-chunk mappings (A.fp.reserved selects; 0 = identity)
+#elif defined(UVS_WAVE_TIMES)           // experiment: workgroup -> trial-chunk mappings (bits 16-23 of A.fp.reserved select; 0 = identity)
 #define UVS_ITEM_END return
     long long chunk = blockIdx.x;
-    {
+    int seg = 0;
+    if (SEG && A.n_seg > 1) {
+        const unsigned nchunks = gridDim.x / (unsigned)A.n_seg;
+        seg = (int)(blockIdx.x / nchunks);
+        chunk = blockIdx.x - (unsigned)seg * nchunks;
+    } else {
+        const int map_ = (A.fp.reserved >> 16) & 0xff;
         const long long nw = gridDim.x, nfull = (nw / 8) * 8;
-        if (A.fp.reserved == 1 && chunk < nfull) chunk = (chunk % 8) * (nfull / 8) + chunk / 8;      // XCD x owns a contiguous eighth of the trials
-        if (A.fp.reserved >= 8 && A.fp.reserved < 16 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (A.fp.reserved - 8)) & 7);   // XCD x writes the 256-byte slot x + r of every 2 KB
-        if (A.fp.reserved >= 16 && A.fp.reserved < 24 && chunk < nfull) chunk = chunk ^ (A.fp.reserved - 16);                             // ... slot x ^ r
-        if (A.fp.reserved == 2 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (chunk >> 3)) & 7);                                    // ... every slot in turn
+        if (map_ == 1 && chunk < nfull) chunk = (chunk % 8) * (nfull / 8) + chunk / 8;      // XCD x owns a contiguous eighth of the trials
+        if (map_ >= 8 && map_ < 16 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (map_ - 8)) & 7);   // XCD x writes the 256-byte slot x + r of every 2 KB
+        if (map_ >= 16 && map_ < 24 && chunk < nfull) chunk = chunk ^ (map_ - 16);                             // ... slot x ^ r
+        if (map_ == 2 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (chunk >> 3)) & 7);                                    // ... every slot in turn
     }
     const long long wave_first = chunk * TPW;
 #else
 #define UVS_ITEM_END return
-    const long long wave_first = (long long)blockIdx.x * TPW;      // first trial of this wavefront (uniform)
+    // Work item = (trial chunk, segment).  Workgroups are dispatched in the order of their ids, so with ids laid out segment-major every
+    // item's predecessor (same chunk, previous segment: an id smaller by the number of chunks) was dispatched before it and runs to its
+    // end without waiting on anything later -- the hardware dispatcher is the work queue (MCKF).
+    long long chunk = blockIdx.x;
+    int seg = 0;
+    if constexpr (SEG) {
+        if (A.n_seg > 1) {
+            const unsigned nchunks = gridDim.x / (unsigned)A.n_seg;
+            seg = (int)(blockIdx.x / nchunks);
+            chunk = blockIdx.x - (unsigned)seg * nchunks;
+        }
+    }
+    const long long wave_first = chunk * TPW;                      // first trial of this wavefront (uniform)
 #endif
     const unsigned tl = lane / L;                                   // trial within the wavefront
     const bool valid = wave_first + tl < A.T;
     const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
+    // segment [k_begin, k_end) of the trial; `fresh`: start from the initial state (first segment, or a later one whose predecessor did not
+    // report within the spin budget -- it then recomputes the trial from step 0, writing the same rows once more: never a deadlock)
+    int k_begin = 0, k_end = K;
+    bool fresh = true, last_seg = true;
+    if constexpr (SEG) {
+        if (A.n_seg > 1) {
+            k_begin = A.seg_first[seg];
+            k_end = A.seg_first[seg + 1];
+            last_seg = seg == A.n_seg - 1;
+            if (seg > 0) {
+                int spins = 0;
+                bool there = false;
+                do {
+                    there = __hip_atomic_load(&A.ws_flags[chunk], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seg;
+                    if (there) break;
+                    __builtin_amdgcn_s_sleep(32);
+                } while (++spins < kSegSpinMax);
+                there = __builtin_amdgcn_readfirstlane((int)there) != 0;          // (every lane ran the acquiring load itself: no further fence)
+                fresh = !there;
+                if (fresh) k_begin = 0;
+            }
+        }
+    }
 
     // per-lane stream cursors (advance by the step stride once per step; components are reached by adding the uniform stride)
     const double *pn = A.noise.p ? A.noise.at(trial, 0, sub) : nullptr;
@@ -648,7 +695,63 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     for (int u = 0; u < JG; ++u) { sn[u] = 0.0; cs[u] = 1.0; }
     double p[PV > 0 ? PV : 1][NP];
     double xr[XREG ? R : 1][N];                                    // X when it lives in registers
-    {
+    double t = fp.dt;
+    int status = UVS_STATUS_SUCCESS, k_done = K;
+    bool alive = true, flagged = false;                          // flagged: a rank-deficient Jacobian was seen -> careful second pass
+#pragma unroll
+    for (int r = 0; r < R; ++r) des[r] = pick_sub<L>(&fp.desired[r * L], sub);
+    // The state of a trial chunk between two of its segments, [field][lane] in the workspace (seg_state_doubles per lane).
+    auto seg_state = [&](auto saving) {
+        constexpr bool SAVE = decltype(saving)::value;
+        if constexpr (SEG) {
+            double *w = A.ws_state + chunk * (long long)(seg_state_doubles(M, N, L) * 64) + lane;
+            // Saving: agent-scope stores (write through this XCD's L2).  Plain stores would need a release fence to become visible to the
+            // XCD that runs the next segment, and on gfx950 that fence is `buffer_wbl2`: a write-back of the whole L2, 4 MB of other
+            // wavefronts' streaming output -- measured at ~55 us per hand-over.
+            auto put = [&](double *at, double v) { __hip_atomic_store(at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto io = [&](double &v) { if constexpr (SAVE) put(w, v); else v = *w; w += 64; };
+#pragma unroll
+            for (int u = 0; u < JG; ++u) { io(q[u]); io(sn[u]); io(cs[u]); }
+#pragma unroll
+            for (int j = 0; j < N; ++j) io(dq[j]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) io(f_prev[r]);
+            io(t);
+#pragma unroll
+            for (int r = 0; r < PV; ++r)
+#pragma unroll
+                for (int e = 0; e < NP; ++e) io(p[r][e]);
+            // the LDS-resident part in batches: all loads of a batch in flight before the first is consumed (one at a time, each restore would
+            // wait out a full memory latency per value)
+            constexpr int NLDS = PL * NP + R * N + 3 * R;
+            auto lds_cell = [&](int i) -> double & {
+                return i < PL * NP ? lds_p[i < PL * NP ? i : 0][lane] : (i < PL * NP + R * N ? lds_x[(i - PL * NP) % (R * N)][lane] : lds_acc[(i - PL * NP - R * N) % (3 * R)][lane]);
+            };
+            constexpr int BATCH = NLDS;                                  // (vmcnt lets 63 of them be in flight at once)
+#pragma unroll
+            for (int b = 0; b < NLDS; b += BATCH) {
+                double tmp[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i)
+                    if (b + i < NLDS) tmp[i] = SAVE ? lds_cell(b + i) : w[(long long)i * 64];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i)
+                    if (b + i < NLDS) { if constexpr (SAVE) put(w + (long long)i * 64, tmp[i]); else lds_cell(b + i) = tmp[i]; }
+                w += (NLDS - b < BATCH ? NLDS - b : BATCH) * 64;
+            }
+            const int bits = (alive ? 1 : 0) | (flagged ? 2 : 0) | (reseed ? 4 : 0) | (status << 8);
+            double word = __hiloint2double(k_done, bits);
+            io(word);
+            if constexpr (!SAVE) {
+                const int b = __double2loint(word);
+                alive = b & 1; flagged = b & 2; reseed = b & 4; status = b >> 8;
+                k_done = __double2hiint(word);
+            }
+        }
+    };
+    if (!fresh) {
+        seg_state(std::false_type{});
+    } else {
         double q_all[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { q_all[j] = *A.q_start.at(trial, 0, j); dq[j] = 0.0; }
@@ -684,7 +787,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            des[r] = pick_sub<L>(&fp.desired[r * L], sub);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (XREG) xr[r][j] = x0[r][j];
@@ -709,16 +811,24 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     double nz_next[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) nz_next[r] = 0.0;
-    if (on_noise && K > 0) {
+    if constexpr (SEG) {
+        if (k_begin > 0) {                                       // a later segment: every stream cursor to its first step
+            if (on_noise) pn += (long long)k_begin * A.noise.sk;
+            if constexpr (XOUT) px += (long long)k_begin * A.x_out.sk;
+            if (on_err) pe += (long long)k_begin * A.err_out.sk;
+            if (on_f) pf += (long long)k_begin * A.f_out.sk;
+            if (on_q) pq += (long long)k_begin * A.q_out.sk;
+            if (on_dq) pd += (long long)k_begin * A.dq_out.sk;
+        }
+        if (!__any(alive)) k_end = k_begin;                      // every trial of the chunk FAILed in an earlier segment
+    }
+    if (on_noise && k_begin < K) {
 #pragma unroll
         for (int r = 0; r < R; ++r) nz_next[r] = pn[r * L * A.noise.sc];
         pn += A.noise.sk;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
 
-    double t = fp.dt;
-    int status = UVS_STATUS_SUCCESS, k_done = K;
-    bool alive = true, flagged = false;                          // flagged: a rank-deficient Jacobian was seen -> careful second pass
 #ifdef UVS_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -737,7 +847,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id_));
         fair_slot = hw_id_ & 1u;                                 // WAVE_ID bit 0
     }
-    for (int k = 0; k < K; ++k) {
+    for (int k = k_begin; k < k_end; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         UVS_STAMP(5);
         if constexpr (FAIR) {
@@ -1216,6 +1326,26 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     return;
 #endif
 
+    if constexpr (SEG) {
+        if (!last_seg) {                                         // hand the chunk to its next segment: state, then the release of the counter
+            seg_state(std::true_type{});
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every write-through store of the wavefront has been acknowledged before ...
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&A.ws_flags[chunk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the counter moves
+#ifdef UVS_WAVE_TIMES
+            if (lane == 0 && A.stats) {
+                unsigned long long wt_last;
+                unsigned hw_id, xcc_id;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_last)::"memory");
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+                double *ws_ = A.stats + 3 * wave_first + 4 * seg;
+                ws_[0] = (double)wt_first; ws_[1] = (double)wt_last; ws_[2] = (double)hw_id; ws_[3] = (double)xcc_id;
+            }
+#endif
+            UVS_ITEM_END;
+        }
+    }
     double s2[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1229,7 +1359,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
     if (!valid) UVS_ITEM_END;
     if (sub == 0) {
+#ifdef UVS_WAVE_TIMES
+        if (A.stats && !(SEG && A.n_seg > 1)) {                 // (segmented: the chunk's slice of `stats` holds the stamps of every segment)
+#else
         if (A.stats) {
+#endif
 #pragma unroll
             for (int c = 0; c < 3; ++c) A.stats[3 * trial + c] = sqrt(s2[c]);
         }
@@ -1240,10 +1374,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_last)::"memory");
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-            A.stats[3 * wave_first + 0] = (double)wt_first;
-            A.stats[3 * wave_first + 1] = (double)wt_last;
-            A.stats[3 * wave_first + 2] = (double)hw_id;
-            A.stats[3 * wave_first + 3] = (double)xcc_id;
+            A.stats[3 * wave_first + 4 * seg + 0] = (double)wt_first;
+            A.stats[3 * wave_first + 4 * seg + 1] = (double)wt_last;
+            A.stats[3 * wave_first + 4 * seg + 2] = (double)hw_id;
+            A.stats[3 * wave_first + 4 * seg + 3] = (double)xcc_id;
         }
 #endif
         if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;

@@ -13,6 +13,10 @@
 #include "uvs_rmckf.h"
 #include "launchers.hpp"
 
+#ifndef UVS_MCKF_TAPER_PCT               // length of the last segment of an MCKF trial in % of the first (linear in between): 100 / 50 / 25 / 10 % measured
+#define UVS_MCKF_TAPER_PCT 10            // 4.32 / 4.12 / 4.07 / 4.04 ms at 8 segments (unsegmented 4.43), 4.96 / 4.91 / 4.73 / 4.64 on alpha = 1.0 (5.51)
+#endif
+
 using namespace uvs_launch;
 
 // ================================================================================================ C ABI
@@ -72,9 +76,55 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap) {
     return cnt;
 }
 
+// Segmented trials (tuned two-lane MCKF kernel).  How many segments a launch of T trials is cut into: MCKF wavefronts differ in length (a
+// trial whose fixed-point iteration keeps iterating costs its whole wavefront the branch), so the last round of a launch of whole trials
+// leaves SIMDs idle for up to a third of a trial.  Bits 8-15 of fp->reserved override (1 = never, n = n segments).
+namespace {
+constexpr int64_t kSimdSlots = 1024;
+int segments_for(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
+    if (!fp || !plant || T <= 0 || fp->method != UVS_METHOD_MCKF || fp->lanes_per_filter < 0 || plant->kind != UVS_PLANT_DH_PINHOLE) return 1;
+    const int L = fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n, fp->method);
+    bool tuned2 = false;
+#define X(M, N, LL) if (fp->m == M && fp->n == N && L == LL && LL == 2) tuned2 = true;
+    UVS_TUNED_SHAPES_A(X) UVS_TUNED_SHAPES_B(X)
+#undef X
+    if (!tuned2) return 1;
+    const int forced = (fp->reserved >> 8) & 0xff;
+    int n = forced;
+    if (!n) {
+        const int64_t chunks = (T * L + 63) / 64;
+        // measured on MI355X (32 trials per wavefront, one wavefront per SIMD): one round or less -- nothing to balance;
+        // up to three rounds -- 8 segments (49 152 trials 4.02 -> 3.15 ms, 65 536: 4.43 -> 4.04, 98 304: 6.46 -> 5.94); beyond -- 4
+        // (131 072: 8.24 -> 7.66, 262 144: 15.6 -> 15.0), where 8 hand-overs per chunk cost more than the shorter tail returns
+        n = chunks <= kSimdSlots ? 1 : (chunks <= 3 * kSimdSlots ? 8 : 4);
+    }
+    if (n > 16) n = 16;
+    if (n > 1 && fp->steps < 8 * n) n = 1;                        // nothing to cut in a short trial
+    return n < 1 ? 1 : n;
+}
+size_t seg_flag_bytes(int64_t chunks) { return (size_t)((chunks * sizeof(int) + 255) / 256) * 256; }
+}  // namespace
+
+int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) { return segments_for(fp, plant, T); }
+
+size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
+    const int n = segments_for(fp, plant, T);
+    if (n <= 1) return 0;
+    const int64_t chunks = (T * 2 + 63) / 64;
+    return seg_flag_bytes(chunks) + (size_t)chunks * uvs::seg_state_doubles(fp->m, fp->n, 2) * 64 * sizeof(double);
+}
+
 int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T, uvs_view q_start, uvs_view noise,
                               uvs_view x0, uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
                               double *stats, int32_t *status, int32_t *k_done, uvs_view x_final, uvs_view p_final, void *stream) {
+    return uvs_rmckf_closed_loop_ws_f64(fp, plant, T, q_start, noise, x0, x_out, err_out, q_out, f_out, dq_out, stats, status, k_done, x_final, p_final,
+                                        nullptr, 0, stream);
+}
+
+int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T, uvs_view q_start, uvs_view noise,
+                                 uvs_view x0, uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
+                                 double *stats, int32_t *status, int32_t *k_done, uvs_view x_final, uvs_view p_final,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
     int L = 0;
     if (int rc = check_params(fp, T, &L)) return rc;
     if (!plant) return fail(UVS_ERR_ARG, "%s", "plant is NULL");
@@ -98,6 +148,29 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
     A.f_out = uvs::to_view(f_out); A.dq_out = uvs::to_view(dq_out);
     A.x_final = uvs::to_view(x_final); A.p_final = uvs::to_view(p_final);
     A.stats = stats; A.status = status; A.k_done = k_done;
+    if (workspace) {                                               // segmented trials, when the caller lent enough memory for them
+        if (((uintptr_t)workspace & 7u) != 0) return fail(UVS_ERR_ARG, "%s", "workspace must be 8-byte aligned");
+        const size_t need = uvs_rmckf_closed_loop_workspace_bytes(fp, plant, T);
+        if (need > 0 && workspace_bytes >= need) {
+            A.n_seg = segments_for(fp, plant, T);
+            // Segment lengths taper linearly towards the end of the trial (the last one UVS_MCKF_TAPER_PCT % of the first): what is left
+            // unbalanced at the end of the launch is one short work item per slot instead of one of average length.
+            const int taper = UVS_MCKF_TAPER_PCT;
+            double w[uvs::kMaxSegments], sum = 0.0;
+            for (int i = 0; i < A.n_seg; ++i) { w[i] = 100.0 - (100.0 - taper) * i / (A.n_seg > 1 ? A.n_seg - 1 : 1); sum += w[i]; }
+            double acc = 0.0;
+            A.seg_first[0] = 0;
+            for (int i = 0; i < A.n_seg; ++i) {
+                acc += w[i];
+                int b = (int)(fp->steps * (acc / sum) + 0.5);
+                if (b <= A.seg_first[i]) b = A.seg_first[i] + 1;
+                A.seg_first[i + 1] = b < fp->steps ? b : fp->steps;
+            }
+            A.seg_first[A.n_seg] = fp->steps;
+            A.ws_flags = (int *)workspace;
+            A.ws_state = (double *)((char *)workspace + seg_flag_bytes((T * 2 + 63) / 64));
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
     // lanes_per_filter 1 / 2 / 4 select the tuned kernel (rmckf_tuned.hpp) where it exists; a negative value forces the generic

@@ -93,6 +93,31 @@ def supported_lanes(m, n):
     return [buf[i] for i in range(min(cnt, 16))]
 
 
+_WORKSPACES = {}
+
+
+def workspace(fp, plant_struct, T, device):
+    """(pointer, bytes) of the scratch buffer uvs_rmckf_closed_loop_ws_f64 wants for this launch -- (None, 0) when it wants none.  One
+    buffer per device and stream, grown on demand and kept: the library allocates nothing itself."""
+    need = int(_lib.lib().uvs_rmckf_closed_loop_workspace_bytes(C.byref(fp), C.byref(plant_struct), T))
+    if need == 0:
+        return None, 0
+    torch = _torch()
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _WORKSPACES[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return buf.data_ptr(), need
+
+
+def launch_closed_loop(fp, plant_struct, T, *args, device=None):
+    """uvs_rmckf_closed_loop_ws_f64 on torch's current stream with this process's cached workspace: ``args`` are the views / pointers of
+    uvs_rmckf_closed_loop_f64 between ``T`` and ``stream``, in the header's order.  Returns the library's return code."""
+    torch = _torch()
+    ws, ws_bytes = workspace(fp, plant_struct, T, device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+    return _lib.lib().uvs_rmckf_closed_loop_ws_f64(C.byref(fp), C.byref(plant_struct), T, *args, ws, ws_bytes, _stream())
+
+
 def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False):
     """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
     ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``)."""
@@ -109,13 +134,14 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
     flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)           # around the launch only: the
+    ws, ws_bytes = workspace(fp, plant_struct, T, dev)
     start.record()                                                                                     # allocations above are not kernel time
-    rc = _lib.lib().uvs_rmckf_closed_loop_f64(
+    rc = _lib.lib().uvs_rmckf_closed_loop_ws_f64(
         C.byref(fp), C.byref(plant_struct), T, flat(q_start), stream_view(noise, layout), flat(x0),
         stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['q'], layout),
         stream_view(out['f'], layout), stream_view(out['dq'], layout),
         out['stats'].data_ptr(), out['status'].data_ptr(), out['k_done'].data_ptr(),
-        flat(out['x_final']), flat(out['p_final']), _stream())
+        flat(out['x_final']), flat(out['p_final']), ws, ws_bytes, _stream())
     stop.record()
     _lib.check(rc)
     out['events'] = (start, stop)
