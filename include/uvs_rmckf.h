@@ -48,6 +48,14 @@ extern "C" {
 enum { UVS_METHOD_ANALYTICAL = 1, UVS_METHOD_KF = 2, UVS_METHOD_MCKF = 3, UVS_METHOD_IMCCKF = 4, UVS_METHOD_GMCKF = 5 };
 enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
 
+/* Option bits of uvs_filter_params.reserved.
+ * UVS_OPT_STRICT_PINV: every control-law solve of the closed loop / of a replay that asks for the commanded dq goes through the careful
+ *   kernels (Householder QR finished by an SVD of the triangular factor with numpy's 1e-15 cutoff, experiment.py:312) instead of only
+ *   the trials the fast kernels' rank watch marks.  The watch sees a vanishing pivot and bad column scaling; it cannot see a Jacobian
+ *   whose columns are pairwise parallel within ~1e-3 in a cascade (Kahan-like; tests/golden/rankdef_gmckf_kahan_c1000: numpy truncates,
+ *   the fast kernels return the plain least-squares command).  Strict mode is several times slower; default off. */
+#define UVS_OPT_STRICT_PINV 1
+
 /* Strided view of a [trial][step][component] array of doubles. */
 typedef struct uvs_view {
     double *base;
@@ -74,8 +82,8 @@ typedef struct uvs_filter_params {
     double reg;                 /* 0.001**2 added to Cy before inversion (:280)                     */
     double fpi_threshold;       /* MCKF fixed-point stop test (:38, :215)                           */
     int32_t fpi_epoch_max;      /* MCKF iteration cap; reaching it skips the correction (:39, :246) */
-    int32_t reserved;           /* option bits, 0 = defaults.  bits 8-15: segments per MCKF trial for                   */
-                                /* uvs_rmckf_closed_loop_ws_f64 (0 = library's choice); all other bits must be 0          */
+    int32_t reserved;           /* option bits, 0 = defaults.  bit 0: UVS_OPT_STRICT_PINV (below).  bits 8-15: segments */
+                                /* per MCKF trial for uvs_rmckf_closed_loop_ws_f64 (0 = library's choice); others: 0      */
     double desired[UVS_MAX_M];  /* desired_f (:21)                                                  */
 } uvs_filter_params;
 

@@ -4,7 +4,7 @@ golden vectors that oracle/gen_golden.py captured from the unmodified reference
 import numpy as np
 import pytest
 
-from conftest import NOISE_KIND, golden_names, load_golden, rel_err
+from conftest import RANKDEF_CMD_TOL, NOISE_KIND, golden_names, load_golden, rel_err
 from oracle import noise_ref, plant_ref, rmckf_block, rmckf_dense
 
 CLOSED = golden_names('closed_')
@@ -148,12 +148,40 @@ RANKDEF_HORIZON = {'rankdef_gmckf_dup_col': 40}
 
 
 def test_rankdef_fixture_inventory():
-    assert RANKDEF == ['rankdef_gmckf_dup_col', 'rankdef_gmckf_rank1', 'rankdef_gmckf_rank4_product', 'rankdef_gmckf_zero_and_scaled_col',
-                       'rankdef_kf_rank4_product']
+    assert RANKDEF == ['rankdef_gmckf_dup_col', 'rankdef_gmckf_kahan_c1000', 'rankdef_gmckf_rank1', 'rankdef_gmckf_rank4_product',
+                       'rankdef_gmckf_scaled_1e12_indep', 'rankdef_gmckf_scaled_1e12_par_1em9', 'rankdef_gmckf_scaled_1e6_par_1em12',
+                       'rankdef_gmckf_zero_and_scaled_col', 'rankdef_kf_rank4_product']
     for name in RANKDEF:
         g = load_golden(name)
         s = np.linalg.svd(g['x0'].reshape(8, 6), compute_uv=False)
-        assert s[-1] <= 1e-15 * s[0] and not g['meta']['params']['initial_guess']      # pinv truncates from the first step on
+        assert not g['meta']['params']['initial_guess']
+        if name == 'rankdef_gmckf_scaled_1e12_indep':                                   # bad scaling alone: numpy keeps every component
+            assert 1e-14 < s[-1] / s[0] < 1e-12
+        else:
+            assert s[-1] <= 1e-15 * s[0]                                                # pinv truncates from the first step on
+
+
+def test_boundary_fixtures_sit_where_the_rank_watch_is_blind_or_not():
+    """what an unpivoted QR shows of the boundary Jacobians, step by step along the reference's own runs (recomputed here
+    from the fixtures' X with numpy).  `diag` = spread of |R_cc| (all the kernels watched until round 3), `entry` = max |R_ij| / min |R_cc|
+    (watched since round 4), gate 2^34; `trunc` = numpy's pinv drops a singular value."""
+    gate = 2.0 ** 34
+    seen = {}
+    for name in ('scaled_1e12_par_1em9', 'scaled_1e6_par_1em12', 'scaled_1e12_indep', 'kahan_c1000'):
+        g = load_golden('rankdef_gmckf_' + name)
+        assert len(g['X_steps']) == 299
+        trunc, diag, entry = [], [], []
+        for x in g['X']:
+            sv = np.linalg.svd(x.reshape(8, 6), compute_uv=False)
+            r = np.abs(np.linalg.qr(x.reshape(8, 6), mode='r'))
+            d = np.diag(r)
+            trunc.append(bool((sv <= 1e-15 * sv.max()).any())), diag.append(d.max() / d.min() >= gate), entry.append(r.max() / d.min() >= gate)
+        seen[name] = (int(np.sum(trunc)), int(np.sum(diag)), int(np.sum(entry)), bool(entry[0]))
+    assert seen['scaled_1e12_par_1em9'] == (299, 0, 299, True)        # truncated at every step; the diagonal never shows it, the entries always
+    t, d, e, first = seen['scaled_1e6_par_1em12']
+    assert t == 299 and d == 0 and first and 20 <= e < 299              # caught at the first step (one mark redoes the whole trial), not at every step
+    assert seen['scaled_1e12_indep'][0] == 0 and seen['scaled_1e12_indep'][2] == 299      # marked although numpy truncates nothing: the careful pass must agree anyway
+    assert seen['kahan_c1000'] == (299, 0, 0, False)                    # no magnitude of the factor shows it: UVS_OPT_STRICT_PINV territory
 
 
 @pytest.mark.parametrize('name', RANKDEF)
@@ -167,7 +195,22 @@ def test_block_replay_matches_reference_on_rank_deficient_jacobians(name):
                                  kernel_bw=p['kernel_bw'], annealing=p['annealing'], k_max=int(meta['t_max'] / meta['dt']))
     h = RANKDEF_HORIZON.get(name, len(g['t']))
     assert rel_err(out['X'][g['X_steps']][:h], g['X'][:h]) <= 1e-11
-    assert rel_err(out['dq_cmd'][:h - 1], g['dq_prev'][1:h]) <= 1e-8
+    assert rel_err(out['dq_cmd'][:h - 1], g['dq_prev'][1:h]) <= RANKDEF_CMD_TOL.get(name, 1e-8)
+
+
+def test_numpy_pinv_is_only_defined_to_cond_eps_on_the_1e12_fixtures():
+    """Why two fixtures carry a loose command gate: one ulp on the reference's own X moves the reference's own command."""
+    def sensitivity(name):
+        g = load_golden(name)
+        worst = 0.0
+        for k in range(0, 299, 7):
+            x, y = g['X'][k].reshape(8, 6), g['err'][k]
+            a, b = np.linalg.pinv(x) @ y, np.linalg.pinv(np.nextafter(x, np.inf)) @ y
+            worst = max(worst, float(np.abs(a - b).max() / np.abs(a).max()))
+        return worst
+    assert 1e-4 < sensitivity('rankdef_gmckf_scaled_1e12_indep') < RANKDEF_CMD_TOL['rankdef_gmckf_scaled_1e12_indep']
+    assert 1e-5 < sensitivity('rankdef_gmckf_scaled_1e12_par_1em9') < RANKDEF_CMD_TOL['rankdef_gmckf_scaled_1e12_par_1em9']
+    assert sensitivity('rankdef_gmckf_scaled_1e6_par_1em12') < 1e-8 and sensitivity('rankdef_gmckf_kahan_c1000') < 1e-12
 
 
 # ---------------------------------------------------------------------------------------------- MCKF fixed-point iteration (fpi_*)

@@ -45,6 +45,17 @@ UVS_DEV double group_sum(double v) {
     if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
+// Largest of the group's non-negative values (NaN-free by construction: callers feed fmax results), on every lane.
+template <int L>
+UVS_DEV double group_max(double v) {
+    if constexpr (L >= 2) v = fmax(v, dpp_mov64<kDppXor1>(v));
+    if constexpr (L >= 4) v = fmax(v, dpp_mov64<kDppXor2>(v));
+    if constexpr (L >= 8) v = fmax(v, dpp_mov64<kDppHalfMirror>(v));
+    if constexpr (L >= 16) v = fmax(v, dpp_mov64<kDppMirror>(v));
+    if constexpr (L >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+    if constexpr (L >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+    return v;
+}
 template <int L>
 UVS_DEV int group_or(int v) {
     if constexpr (L >= 2) v |= dpp_mov32<kDppXor1>(v);
@@ -409,14 +420,18 @@ struct Rows {
 // The reference solves the control law with numpy's pinv (experiment.py:312): SVD, singular values <= 1e-15 * sigma_max dropped.
 // For full-rank J that equals the Householder least-squares solution the kernels compute; for (numerically) rank-deficient J it is
 // the minimum-norm solution, which an unpivoted QR does not give.  Split of work:
-//   * every least-squares solve watches the spread of |R_cc| (all kernels, a handful of integer instructions): a spread of 2^34 or
-//     more -- or an exactly zero column next to non-zero ones -- marks the trial UVS_STATUS_SUSPECT;
-//     KNOWN GAP: that diagonal is not rank-revealing.  A Jacobian whose columns are badly scaled AND nearly parallel can hide a condition
-//     number beyond 1e15 behind an unremarkable diagonal ([[1, 1e20], [0, 1]]); the hot kernels then return the plain least-squares
-//     solution where numpy would truncate.  Watching max |R_ij| as well costs ~60 instructions per step in the headline kernel (4 %);
-//     the estimated Jacobians of this path have columns within a few decades of each other, and the rank-deficient fixtures of the
-//     reference (tests/golden/rankdef_*) are all caught by the diagonal.  Normal-equation solvers (wide kernel, control wavefronts of
-//     the replay) mark at a spread of 2^20 already and are accurate to ~6e-9 in the command up to cond 1e6;
+//   * every least-squares solve watches two magnitudes of the triangular factor (all kernels; ~25 instructions per step in the headline
+//     kernel): the smallest |R_cc| and the largest |R_ij| of the whole factor.  max |R_ij| <= sigma_max and min |R_cc| >= sigma_min, so their
+//     ratio is a lower bound of the condition number; a ratio of 2^34 or more -- or an exactly zero column next to non-zero ones -- marks
+//     the trial UVS_STATUS_SUSPECT.  That catches rank deficiency (a vanishing pivot) and bad column scaling, also where the two hide each
+//     other: [[1, 1e20], [0, 1]] has an unremarkable diagonal and condition 1e40 (fixtures tests/golden/rankdef_gmckf_scaled_*: a column
+//     scaled by 1e12 / 1e6 that is parallel to another within 1e-9 / 1e-12 -- numpy truncates, the diagonal alone shows a spread of 1e3).
+//     WHAT NO SUCH WATCH SEES: a factor with every entry of ordinary size whose inverse still explodes (Kahan-like: unit diagonal, all
+//     off-diagonals -1000, condition 3e18; fixture rankdef_gmckf_kahan).  The fast kernels return the plain least-squares command there,
+//     numpy truncates.  It takes columns that are pairwise parallel within 1e-3 in a fixed cascade; callers who must have numpy's answer
+//     there too set UVS_OPT_STRICT_PINV in fp->reserved, which sends EVERY trial through the careful kernels below (several times slower).
+//     Normal-equation solvers (wide kernel, control wavefronts of the replay) mark at a spread of 2^20 already and are accurate to ~6e-9
+//     in the command up to cond 1e6;
 //   * suspect trials are re-run from their first step by the `careful` instantiation of the generic kernels, launched right behind
 //     the main kernel by the C ABI, whose control law finishes the same QR with a one-sided Jacobi SVD of the n x n factor R
 //     (pinv(J) y = pinv(R) Q^T y, same singular values as J) and applies numpy's cutoff.  The hot kernels stay free of that code.
@@ -431,6 +446,15 @@ struct Spread {
         const unsigned e = (unsigned)__double2hiint(n2);
         lo = e < lo ? e : lo;
         hi = e > hi ? e : hi;
+    }
+    // The largest magnitude mx >= 0 among the entries of the factor (running fmax of |R_ij|; NaNs drop out of fmax and are caught by the
+    // column norms): its square's high dword is 2 hi(mx) - 0x3ff00000 up to the mantissa product, i.e. within a factor 2 -- plenty for
+    // a 2^34 gate.  Only raises `hi`: the smallest pivot stays the diagonal's.
+    UVS_DEV void add_largest(double mx) {
+        const unsigned h = (unsigned)__double2hiint(mx);
+        unsigned e2 = h >= 0x20000000u ? 2u * h - 0x3ff00000u : 0u;             // (below 2^-511 the square underflows: no information)
+        e2 = e2 > 0x7ff00000u ? 0x7ff00000u : e2;                               // a square beyond the range reads as +inf ("suspect"), never as NaN ("non-finite")
+        hi = e2 > hi ? e2 : hi;
     }
     // lo == 0: a column vanished altogether (all of them when hi == 0 too, J = 0, where the plain solve would divide 0 by 0)
     UVS_DEV bool suspect() const { return hi - lo >= kSuspectSpread || lo == 0u; }
@@ -510,12 +534,20 @@ constexpr unsigned kSuspectSpreadNormalEq = 40u << 20;
 
 // In place: G[at(j, i)], i > j, becomes L_ij; rs[j] = 1 / L_jj.  Returns the suspect verdict: pivots spread too far, or one of them
 // is not a positive normal number (zero / negative: breakdown; inf / NaN).
-template <int N>
+// COLS = false leaves the column norms out of the watch (pivots only): the wide-shape kernel sits at 505 of 512 registers and spills with them.
+template <int N, bool COLS = true>
 UVS_DEV bool chol_factor(double (&G)[Sym<N>::NP], double (&rs)[N]) {
     Spread spread;
+    // the largest squared column norm of J (the diagonal of G before it is touched) bounds sigma_max^2 from below just like max R_ij^2 does
+    // in the QR solvers -- and costs no arithmetic and no live range here (tracking max |L_ij| cost the wide kernel 30 registers and spills)
+    unsigned col_hi = 0u;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double d = G[Sym<N>::at(j, j)];
+        if constexpr (COLS) {                                    // squared norm of column j of J, read where it is consumed anyway
+            const unsigned e = (unsigned)__double2hiint(d);
+            col_hi = (e > col_hi && e <= 0x7ff00000u) ? e : col_hi;   // (a NaN norm is left to the pivot, which turns NaN with it)
+        }
 #pragma unroll
         for (int k = 0; k < j; ++k) d = fma(-G[Sym<N>::at(k, j)], G[Sym<N>::at(k, j)], d);
         spread.add(d);
@@ -530,6 +562,7 @@ UVS_DEV bool chol_factor(double (&G)[Sym<N>::NP], double (&rs)[N]) {
             G[Sym<N>::at(j, i)] = v * r;
         }
     }
+    spread.hi = col_hi > spread.hi ? col_hi : spread.hi;
     return spread.hi - spread.lo >= kSuspectSpreadNormalEq || spread.lo == 0u || spread.hi >= 0x7ff00000u;
 }
 
@@ -561,6 +594,7 @@ UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
     constexpr int R = M / L;
     double diag[N];
     double rcc[CAREFUL ? N : 1];                                 // R_cc, kept only for the careful finish
+    double rmax = 0.0;                                           // largest |R_ij| seen off the diagonal
     Spread spread;
 #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -599,9 +633,11 @@ UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
                 a[r][j] = below ? fma(-d, a[r][c], a[r][j]) : a[r][j];
             }
             a[prow][j] = mine ? fma(-d, vp, a[prow][j]) : a[prow][j];
+            if (j < N) rmax = fmax(rmax, fabs(a[prow][j]));          // row c of R on its owner (elsewhere: some row not larger than its column's norm)
         }
         diag[c] = (denom > 0.0) ? ((piv >= 0.0) ? -rn : rn) : 0.0;  // 1 / R_cc (0 marks a zero column)
     }
+    spread.add_largest(group_max<L>(rmax));
     const bool suspect = spread.suspect();
     if constexpr (CAREFUL) {
         // pinv(J) y = pinv(R) (Q^T y)[0:N]: gather the triangular factor and the transformed right-hand side on every lane of the group
@@ -641,6 +677,7 @@ template <int M, int N, bool CAREFUL = false>
 UVS_DEV bool lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&sol)[N]) {
     double b[N][M];                                               // J^T, overwritten by R (upper) and v (lower)
     double vp[M], tau[M], diag[M];
+    double wmax = 0.0;
     Spread spread;
 #pragma unroll
     for (int i = 0; i < M; ++i)
@@ -666,10 +703,12 @@ UVS_DEV bool lstsq_wide(const double (&J)[M][N], const double (&y)[M], double (&
             for (int r = c + 1; r < N; ++r) d = fma(b[r][c], b[r][j], d);
             d *= tau[c];
             b[c][j] = fma(-d, vp[c], b[c][j]);
+            wmax = fmax(wmax, fabs(b[c][j]));
 #pragma unroll
             for (int r = c + 1; r < N; ++r) b[r][j] = fma(-d, b[r][c], b[r][j]);
         }
     }
+    spread.add_largest(wmax);
     // R^T w = y (forward substitution), then sol = Q [w; 0] = H_0 .. H_{M-1} [w; 0]
     double w[N];
 #pragma unroll

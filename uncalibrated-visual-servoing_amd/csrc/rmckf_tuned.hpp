@@ -451,6 +451,7 @@ template <int M, int N, int L>
 UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N], bool &nonfinite) {
     constexpr int R = M / L;
     double rdiag[N];
+    double rmax = 0.0;
     Spread spread;
 #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -480,11 +481,19 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
             for (int r = m + 1; r < R; ++r) d = fma(a[r][c], a[r][j], d);
             d = pair_sum<L>(d) * tau;
             a[m][j] = fma(-d, vm, a[m][j]);
+            // row c of R is final on its owner lane (the partner holds a row that is finished already, or one whose entries its column's
+            // norm bounds): the running largest |R_cj|, one v_max_f64 with |.| modifiers per entry (see Spread::add_largest)
+#ifndef UVS_NO_ENTRY_WATCH             // experiment builds: A/B of the watch's cost
+            if (j < N) rmax = fmax(rmax, fabs(a[m][j]));
+#endif
 #pragma unroll
             for (int r = m + 1; r < R; ++r) a[r][j] = fma(-d, a[r][c], a[r][j]);
         }
         rdiag[c] = -copysign(rn, piv);                                  // 1 / R_cc straight from the rsqrt
     }
+    if constexpr (L > 1) rmax = fmax(rmax, dpp_quad<kSwapPair>(rmax));
+    if constexpr (L == 4) rmax = fmax(rmax, dpp_quad<kSwapHalf>(rmax));
+    spread.add_largest(rmax);
 #pragma unroll
     for (int c = N - 1; c >= 0; --c) {
         const int m = c / L, owner = c % L;

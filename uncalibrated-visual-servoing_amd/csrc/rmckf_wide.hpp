@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
         UVS_WIDE_FENCE();
         double rs[N];
-        const bool suspect = chol_factor<N>(G, rs);
+        const bool suspect = chol_factor<N, false>(G, rs);       // (pivot spread only: no register left for the column-norm watch, see chol_factor)
         flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
         chol_solve_inplace<N>(G, rs, b);                           // s0
         double c[N];

@@ -179,6 +179,10 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
                            (fp->method == UVS_METHOD_MCKF && L == 2)) && fp->lanes_per_filter >= 0;
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
+    if (fp->reserved & UVS_OPT_STRICT_PINV) {                      // numpy's pinv on every solve: mark every trial, the careful pass below is the only pass
+        if (hipMemsetD32Async((hipDeviceptr_t)status, uvs::UVS_STATUS_SUSPECT, (size_t)T, s) != hipSuccess) return check_launch("strict pinv: marking the trials");
+        launched = true;
+    }
     if (!launched && tuned_ok) launched = closed_wide(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched && tuned_ok) launched = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
@@ -219,6 +223,10 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     // registers, two wavefronts per SIMD (library default, or lanes_per_filter = 4)
     if (tuned_method && !dqcmd_out.base && (fp->lanes_per_filter == 0 || fp->lanes_per_filter == 4))
         launched = replay_rows(fp->m, fp->n, fp->method, fp->lanes_per_filter == 0, x_out.base != nullptr, err_out.base != nullptr, T, s, A);
+    if ((fp->reserved & UVS_OPT_STRICT_PINV) && dqcmd_out.base) {   // numpy's pinv on every solve: the careful pass below is the only pass
+        if (hipMemsetD32Async((hipDeviceptr_t)status, uvs::UVS_STATUS_SUSPECT, (size_t)T, s) != hipSuccess) return check_launch("strict pinv: marking the trials");
+        launched = true;
+    }
     // with the commanded dq (library default lanes, KF / RMCKF, X and err wanted too): the same estimator wavefronts + control wavefronts
     if (!launched && tuned_method && dqcmd_out.base && x_out.base && err_out.base && fp->lanes_per_filter == 0)
         launched = replay_rows_cmd(fp->m, fp->n, fp->method, T, s, A);
