@@ -162,22 +162,40 @@ def cpu_baseline(q_starts, budget_trials_per_core=256):
 
 
 # ---------------------------------------------------------------------------------------------- main
-def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T, K, M, N, reps=20):
+def replay_side_measurement(torch, engine, uvs_amd, fp_closed, plant, q_start, x_buf, err_buf, T, K, M, N, reps=20):
     """Replay mode (SURVEY 8d kernel microbenchmark): the estimator (+ control law) over recorded feature / joint-delta streams,
-    the I/O north_star prices: read f and dq, write X and err.  Synthetic consistent streams f_{k+1} = f_k + J dq_k dt + noise built on
-    the device; reuses the closed-loop run's output buffers.  Reported next to, never as, the closed-loop `value`."""
+    the I/O north_star prices: read f and dq, write X and err.  Inputs per SURVEY 8d "replay-mode synthetic inputs", built on the device:
+    per trial t, J_true = the analytic initial-guess matrix at the trial's jittered q_start (one 1-step launch of the closed loop returns it
+    together with the noise-free features f_0); dq_k = dq_0 exp(-lambda k dt) + N(0, 1e-3^2) with dq_0 ~ N(0, 0.2^2); f_k = f_{k-1} +
+    J_true dq_k dt, observed as f_k + noise_k.  Random streams: the library's NoiseProfiler-compatible generator seeded 987654 + t
+    (white noise for dq_0 and the dq jitter, alpha-stable alpha = 1.5 for the observation noise) -- numpy PCG64 streams of seed
+    987654 + t + 10 i (noise.py:66-70), not one PCG64(987654 + t) per trial: 65 536 host generators would cost the bench minutes.
+    Reuses the closed-loop run's output buffers.  Reported next to, never as, the closed-loop `value`."""
     import ctypes as C
     dev = x_buf.device
+    NT = uvs_amd.NoiseType
+    seeds = np.arange(T, dtype=np.uint64) + np.uint64(987654)
+    lam, dt = fp_closed.gain, fp_closed.dt
+    fp1 = engine.make_params(M, N, 'GMCKF', fp_closed.kernel_bw, False, dt, dt * fp_closed.k_max, lam, list(fp_closed.desired)[:M], True, 0, 1)
+    first = engine.closed_loop(fp1, plant, q_start, None, want=('f',), final_state=True)
+    J = first['x_final'].view(T, M, N).permute(1, 2, 0).contiguous()                 # [m][n][trial]
+    f0 = first['f'][0].clone()                                                       # [m][trial]
+    del first
+    white = uvs_amd.noise_device.generate(NT.WHITE_NOISE, dict(std=1.0), seeds, N, K + 1, layout='kct', device=dev)      # [K + 1][n][trial]
+    decay = torch.exp(-lam * dt * torch.arange(K, device=dev, dtype=torch.float64))
+    dq = 0.2 * white[0][None] * decay[:, None, None] + 1e-3 * white[1:]
+    del white
+    obs = uvs_amd.noise_device.generate(NT.ALPHA_STABLE, dict(alpha=ALPHA, beta=0, gamma=1, delta=0), seeds + np.uint64(1 << 20), M, K + 1, layout='kct', device=dev)
+    f = torch.empty((K + 1, M, T), device=dev, dtype=torch.float64)
+    clean = f0
+    f[0] = clean + obs[0]
+    for k in range(K):
+        clean = clean + torch.einsum('mnt,nt->mt', J, dq[k]) * dt
+        f[k + 1] = clean + obs[k + 1]
+    del obs, clean
     g = torch.Generator(device=dev)
     g.manual_seed(987654)
-    rnd = lambda *shape: torch.randn(shape, device=dev, dtype=torch.float64, generator=g)      # noqa: E731
-    J = rnd(M, N, T) * 50
-    dq = rnd(K, N, T) * 0.2
-    f = torch.empty((K + 1, M, T), device=dev, dtype=torch.float64)
-    f[0] = 128 + 20 * rnd(M, T)
-    for k in range(K):
-        f[k + 1] = f[k] + torch.einsum('mnt,nt->mt', J, dq[k]) * 0.05 + rnd(M, T)
-    x0 = (J + 5 * rnd(M, N, T)).permute(2, 0, 1).reshape(T, M * N).contiguous()
+    x0 = (J * (1 + 0.05 * torch.randn(J.shape, device=dev, dtype=torch.float64, generator=g))).permute(2, 0, 1).reshape(T, M * N).contiguous()
     del J
     fp = engine.make_params(M, N, 'GMCKF', fp_closed.kernel_bw, bool(fp_closed.annealing), fp_closed.dt, fp_closed.dt * fp_closed.k_max, fp_closed.gain,
                             list(fp_closed.desired)[:M], False, 0, K)
@@ -215,6 +233,8 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, x_buf, err_buf, T
                      'LDS-transposed 1 KB stores)')
     out['streams'] = ('read f (m) + dq (n), write X (mn) + err (m) [+ commanded dq (n)] per update; [step][component][trial], estimator_only_records: per-trial records '
                       '[step][trial][component]')
+    out['inputs'] = ('SURVEY 8d: J_true = analytic initial guess at the jittered q_start, dq_k = dq_0 exp(-lambda k dt) + N(0, 1e-3^2), f_k = f_{k-1} + J_true dq_k dt + '
+                     'alpha-stable observation noise, X0 = J_true (1 + 5 % noise); NoiseProfiler-compatible device streams seeded 987654 + t')
     return out
 
 
@@ -783,7 +803,7 @@ def main():
         side_ok = world == 1 and headline_shape and not args.no_side
         replay = None
         if world == 1 and args.config == 2 and not args.no_replay and not args.e2e and not args.stats_only and args.layout == 'kct' and args.lanes in (0, 2):
-            replay = replay_side_measurement(torch, engine, uvs_amd, fp, bufs['x'], bufs['err'], T, K, M, N)
+            replay = replay_side_measurement(torch, engine, uvs_amd, fp, plant, q0, bufs['x'], bufs['err'], T, K, M, N)
         others = None
         if side_ok and not args.e2e:
             # the reference's other three estimators on the headline workload: same inputs, same streams logged;
