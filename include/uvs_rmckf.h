@@ -238,7 +238,8 @@ int uvs_noise_kernel_variant(const uvs_noise_params *np);
 /*
  * Test hook: evaluates the library's fp64 helper functions on the device so that tests can bound their error against
  * numpy.  which: 0 fast reciprocal, 1 sqrt, 2 rsqrt, 3 sin, 4 cos (bounded-argument sincos with library fallback), 5 exp,
- * 6 exp for non-positive arguments, 7 log (own routine on normal positive arguments, library elsewhere), 8 exp with clamped argument.
+ * 6 exp for non-positive arguments, 7 log (own routine on normal positive arguments, library elsewhere), 8 exp with clamped argument,
+ * 9 / 10 sin / cos of 0.7 + x by the short angle-addition polynomials (|x| <= 0.1), 11 / 12 by the long ones (|x| <= 1).
  */
 int uvs_debug_math_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
 

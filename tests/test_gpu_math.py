@@ -82,3 +82,15 @@ def test_exp_clamped_full_range():
         want = np.exp(edge)
     assert got[0] == 1.0 and abs(got[1] / want[1] - 1) < 1e-14 and np.all(np.isinf(got[2:6])) and np.all(got[6:] == 0.0)
     assert np.isnan(_eval(8, np.array([np.nan]))[0])
+
+
+def test_incremental_sincos_both_tiers():
+    """sin / cos carried by the addition theorems (rmckf_math.hpp: sincos_advance for joint steps up to 0.1 rad, sincos_advance_wide up to
+    1 rad -- config 3's held outliers): a few ulp of the pair's own magnitude, measured against numpy at the angle 0.7."""
+    rng = np.random.default_rng(3)
+    for which_s, which_c, bound in ((9, 10, 0.1), (11, 12, 1.0)):
+        d = np.concatenate([rng.uniform(-bound, bound, 200000), [0.0, bound, -bound, 1e-300, -1e-9]])
+        s, c = _eval(which_s, d), _eval(which_c, d)
+        # the pair starts 1 ulp off the true sin / cos of 0.7 (decimal constants); what is bounded is the absolute error on the unit circle
+        assert np.abs(s - np.sin(0.7 + d)).max() <= 4e-16 and np.abs(c - np.cos(0.7 + d)).max() <= 4e-16
+        assert np.abs(s * s + c * c - 1.0).max() <= 6e-16

@@ -45,6 +45,11 @@ __global__ __launch_bounds__(256) void debug_math_kernel(int which, long long n,
         case 6: y[i] = exp_nonpos(v); break;
         case 7: y[i] = log_any(v); break;
         case 8: y[i] = exp_clamped(v); break;
+        // 9-12: the tracked (sin, cos) pair of the angle 0.7 rotated by v -- short polynomials (|v| <= 0.1), long ones (|v| <= 1)
+        case 9: s = 0.64421768723769102; c = 0.76484218728448850; sincos_advance(s, c, v); y[i] = s; break;
+        case 10: s = 0.64421768723769102; c = 0.76484218728448850; sincos_advance(s, c, v); y[i] = c; break;
+        case 11: s = 0.64421768723769102; c = 0.76484218728448850; sincos_advance_wide(s, c, v); y[i] = s; break;
+        case 12: s = 0.64421768723769102; c = 0.76484218728448850; sincos_advance_wide(s, c, v); y[i] = c; break;
         default: y[i] = exp(v); break;
     }
 }

@@ -178,6 +178,44 @@ UVS_DEV void sincos_advance(double &s, double &c, double d) {
     c = c1;
 }
 
+// Second tier: the same rotation for kSinCosStepMax < |d| <= kSinCosStepMax2 (Taylor to d^19 / d^18: truncation < 2e-20 at 1 rad), 27
+// instructions.  Config 3 with the outlier hold drives 14 % of the joint steps past 0.1 rad -- 95 % of the wavefront-steps hold such a trial --
+// and re-seeds three joints from the angle (47 instructions each) on every one of them.  Built and measured in round 4 (A/B on one box,
+// profiles/r04/sincos_tier_ab.txt): config 3 with the hold 12.88 / 12.74 -> 12.68 / 12.63 ms, but config 3 without it 12.03 / 12.22 ->
+// 12.17 / 12.39 and the headline 3.149 / 3.145 -> 3.184 / 3.152: keeping the pre-step pair for the per-lane choice costs every step more than
+// the held outliers return.  OFF by default (0); -DUVS_SINCOS_STEPMAX2=1.0 builds it.
+#ifndef UVS_SINCOS_STEPMAX2
+#define UVS_SINCOS_STEPMAX2 0.0
+#endif
+constexpr double kSinCosStepMax2 = UVS_SINCOS_STEPMAX2;
+UVS_DEV void sincos_advance_wide(double &s, double &c, double d) {
+    const double z = d * d;
+    double ps = -8.2206352466243295e-18;                   // -1/19!
+    ps = fma(ps, z, 2.8114572543455206e-15);               // 1/17!
+    ps = fma(ps, z, -7.6471637318198164e-13);              // -1/15!
+    ps = fma(ps, z, 1.6059043836821613e-10);               // 1/13!
+    ps = fma(ps, z, -2.5052108385441720e-08);              // -1/11!
+    ps = fma(ps, z, 2.7557319223985893e-06);               // 1/9!
+    ps = fma(ps, z, -1.984126984126984e-04);               // -1/7!
+    ps = fma(ps, z, 8.333333333333333e-03);                // 1/5!
+    ps = fma(ps, z, -1.6666666666666666e-01);              // -1/3!
+    const double sd = fma(d * z, ps, d);                   // sin d
+    double pc = -1.5619206968586225e-16;                   // -1/18!
+    pc = fma(pc, z, 4.7794773323873853e-14);               // 1/16!
+    pc = fma(pc, z, -1.1470745597729725e-11);              // -1/14!
+    pc = fma(pc, z, 2.08767569878681e-09);                 // 1/12!
+    pc = fma(pc, z, -2.755731922398589e-07);               // -1/10!
+    pc = fma(pc, z, 2.48015873015873e-05);                 // 1/8!
+    pc = fma(pc, z, -1.388888888888889e-03);               // -1/6!
+    pc = fma(pc, z, 4.166666666666666e-02);                // 1/4!
+    pc = fma(pc, z, -0.5);
+    const double m = z * pc;                               // cos d - 1
+    const double s1 = s + fma(s, m, c * sd);
+    const double c1 = c + fma(c, m, -(s * sd));
+    s = s1;
+    c = c1;
+}
+
 // Range at which sincos_bounded hands over to the library routine (exact huge-argument reduction).
 constexpr double kSinCosBoundedMax = 1.0e5;
 

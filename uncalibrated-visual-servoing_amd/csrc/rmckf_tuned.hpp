@@ -1312,11 +1312,36 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
         UVS_STAMP(3);                                            // logs + statistics
         if constexpr (UVS_INC_SINCOS && DH) {
+            if constexpr (kSinCosStepMax2 > kSinCosStepMax) {
+                // Two tiers, chosen PER LANE (the wavefront only shares the branch, so a trial's bits do not depend on its neighbours): steps up
+                // to 0.1 rad by the short polynomials, steps up to 1 rad by the long ones, anything else re-seeds from the angle at the next step.
+                double dstep[JG], s_old[JG], c_old[JG];
+                bool wide = false;
 #pragma unroll
-            for (int u = 0; u < JG; ++u) {
-                const double d = dq_own[u] * fp.dt;
-                reseed |= !(fabs(d) <= kSinCosStepMax);             // too large for the polynomials, or not finite: re-seed at the next step
-                sincos_advance(sn[u], cs[u], d);
+                for (int u = 0; u < JG; ++u) {
+                    dstep[u] = dq_own[u] * fp.dt;
+                    wide |= !(fabs(dstep[u]) <= kSinCosStepMax);
+                    reseed |= !(fabs(dstep[u]) <= kSinCosStepMax2);   // too large for either tier, or not finite
+                    s_old[u] = sn[u];
+                    c_old[u] = cs[u];
+                    sincos_advance(sn[u], cs[u], dstep[u]);
+                }
+                if (__any(wide)) {
+#pragma unroll
+                    for (int u = 0; u < JG; ++u) {
+                        const bool mid = !(fabs(dstep[u]) <= kSinCosStepMax);
+                        sincos_advance_wide(s_old[u], c_old[u], dstep[u]);
+                        sn[u] = mid ? s_old[u] : sn[u];
+                        cs[u] = mid ? c_old[u] : cs[u];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < JG; ++u) {
+                    const double d = dq_own[u] * fp.dt;
+                    reseed |= !(fabs(d) <= kSinCosStepMax);             // too large for the polynomials, or not finite: re-seed at the next step
+                    sincos_advance(sn[u], cs[u], d);
+                }
             }
         }
 #pragma unroll
