@@ -228,6 +228,42 @@ def replay_side_measurement(torch, engine, uvs_amd, fp_closed, plant, q_start, x
         gbs = updates * b_alg / (avg * 1e-3) / 1e9
         out[name] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b_alg, 'achieved': gbs, 'unit': 'GB/s',
                      'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item())}
+    # ---- the single-precision measured variant: the same streams rounded to fp32, fp32 state; lower precision, never `value`
+    if lay == 'ktc':
+        f, dq = f.permute(0, 2, 1), dq.permute(0, 2, 1)                                  # back to [step][component][trial]
+    f, dq = f.contiguous(), dq.contiguous()
+    f32, dq32, x032 = f.to(torch.float32), dq.to(torch.float32), x0.to(torch.float32).contiguous()
+    x64 = engine.alloc_stream(T, 8, M * N, 'kct', dev)                                # fp64 X of the first 8 steps for the deviation figure
+    fp8 = engine.make_params(M, N, 'GMCKF', fp_closed.kernel_bw, bool(fp_closed.annealing), fp_closed.dt, fp_closed.dt * fp_closed.k_max, fp_closed.gain,
+                             list(fp_closed.desired)[:M], False, 0, 8)
+    uvs_amd._lib.check(uvs_amd.lib().uvs_rmckf_replay_f64(C.byref(fp8), T, engine.stream_view(f, 'kct'), engine.stream_view(dq, 'kct'), flat,
+                                                          engine.stream_view(x64, 'kct'), NV, NV, NV, status.data_ptr(), k_done.data_ptr(), NV, NV,
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    del f, dq
+    x32 = torch.empty((K, M * N, T), dtype=torch.float32, device=dev)
+    e32 = torch.empty((K, M, T), dtype=torch.float32, device=dev)
+    flat32 = uvs_amd._lib.View(x032.data_ptr(), x032.stride(0), 0, x032.stride(1))
+    ms = []
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = uvs_amd.lib().uvs_rmckf_replay_f32(C.byref(fp), T, engine.stream_view(f32, 'kct'), engine.stream_view(dq32, 'kct'), flat32, engine.stream_view(x32, 'kct'),
+                                               engine.stream_view(e32, 'kct'), status.data_ptr(), k_done.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        uvs_amd._lib.check(rc)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    avg = float(np.mean(ms[1:]))
+    updates = int(k_done.sum().item())
+    b32 = 4 * (2 * M + N + M * N)
+    gbs = updates * b32 / (avg * 1e-3) / 1e9
+    dev8 = float(((x32[:8].double() - x64).abs().amax() / x64.abs().amax()).item())
+    out['estimator_only_f32'] = {'updates_per_s': updates / (avg * 1e-3), 'avg_kernel_ms': avg, 'algorithmic_bytes_per_update': b32, 'achieved': gbs, 'unit': 'GB/s',
+                                 'frac': gbs / HBM_PEAK_GBS, 'failed_trials': int((status != 0).sum().item()), 'dtype': 'f32',
+                                 'x_rel_deviation_from_f64_first_8_steps': dev8,
+                                 'note': 'LOWER PRECISION, measured variant only (SURVEY 8d): fp32 streams and fp32 state, v_pk_fma_f32; per-step X deviates ~1e-6 from the fp64 '
+                                         'reference (tests/test_gpu_replay_f32.py bounds it at 1e-5, open loop); never `value`, no closed-loop path'}
+    del x32, e32, f32, dq32, x64
     out['kernel'] = ('estimator_and_control_law: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE,CW=2> (4 estimator + 2 control-law wavefronts per 64 trials); estimator_only: replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE> '
                      '(row groups of a filter in the 4 wavefronts of a 64-trial workgroup, 2 wavefronts/SIMD); estimator_only_records: replay_rows_kernel<...,REC> (4 lane groups, '
                      'LDS-transposed 1 KB stores)')

@@ -177,6 +177,20 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
                          int32_t *status, int32_t *k_done, uvs_view x_final, uvs_view p_final, void *stream);
 
 /*
+ * Single-precision estimator-only replay (SURVEY.md 8d "fp32 variant: report measured error"): the estimator of experiment.py:166-297 over
+ * recorded streams with fp32 streams AND fp32 state, (8,6), KF / IMCC-KF / GMCKF.  A MEASURED LOWER-PRECISION VARIANT, not a drop-in: per-step
+ * X deviates from the reference's fp64 runs by ~1e-6 relative (bounded at 1e-5 by tests/test_gpu_replay_f32.py), and no control law is
+ * solved.  Views as in uvs_rmckf_replay_f64 with float elements (strides in floats); f has K + 1 rows, dq K rows, x0 one row.
+ *   x_out [T][K][m*n], err_out [T][K][m] out (base NULL to skip); status / k_done [T] int32 out (NULL to skip; FAIL = non-finite X)
+ */
+typedef struct uvs_view_f32 {
+    float *base;
+    int64_t trial_stride, step_stride, comp_stride;
+} uvs_view_f32;
+int uvs_rmckf_replay_f32(const uvs_filter_params *fp, int64_t T, uvs_view_f32 f, uvs_view_f32 dq, uvs_view_f32 x0,
+                         uvs_view_f32 x_out, uvs_view_f32 err_out, int32_t *status, int32_t *k_done, void *stream);
+
+/*
  * One estimator + control step for T filters whose state lives in HBM between calls: what
  * Experiment.run() does between getCameraImage() and setJointsPos() (experiment.py:166-312) when
  * the robot is external (live simulator).  All arrays contiguous, trial-major.

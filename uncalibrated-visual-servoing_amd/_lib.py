@@ -64,6 +64,7 @@ SYMBOLS = {
     'uvs_rmckf_closed_loop_segments': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_closed_loop_workspace_bytes': (C.c_size_t, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_replay_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 7 + [_VP] * 2 + [View] * 2 + [_VP]),
+    'uvs_rmckf_replay_f32': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 5 + [_VP] * 2 + [_VP]),
     'uvs_rmckf_step_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [_VP] * 5 + [_I32, _I32] + [_VP] * 4 + [_VP]),
     'uvs_stats_reduce_f64': (C.c_int, [_I64, _I32, _I32, View, _VP, _VP, _VP, _VP]),
     'uvs_debug_math_f64': (C.c_int, [_I32, _I64, _VP, _VP, _VP]),
@@ -115,7 +116,7 @@ def view_of(tensor, dims):
     [step][comp][trial] tensor is view_of(t, (2, 0, 1)); use None for an absent axis (stride 0)."""
     if tensor is None:
         return View(None, 0, 0, 0)
-    assert tensor.dtype.is_floating_point and tensor.element_size() == 8, 'fp64 tensors only'
+    assert tensor.dtype.is_floating_point and tensor.element_size() in (4, 8), 'fp64 tensors (fp32 for uvs_rmckf_replay_f32)'
     strides = [0 if d is None else tensor.stride(d) for d in dims]
     return View(tensor.data_ptr(), *strides)
 

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include "rmckf_device.hpp"
 
+namespace uvs { struct ReplayArgs32; }
+
 // (m, n, lanes-per-filter) instantiations of the generic templates; the first listed L of a shape is its default.
 #ifdef UVS_QUICK                      // experiment builds (make quick): the headline shape only, compiles in seconds
 #define UVS_SHAPES_A(X) X(8, 6, 2) X(8, 6, 4)
@@ -53,6 +55,8 @@ bool replay_careful_b(int m, int n, int64_t T, hipStream_t s, const uvs::ReplayA
 bool replay_tuned(int m, int n, int method, bool xo, bool cmd, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool replay_rows_cmd(int m, int n, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
 bool replay_rows(int m, int n, int method, bool bywave, bool xo, bool eo, int64_t T, hipStream_t s, const uvs::ReplayArgs &A);
+// single-precision estimator-only replay (rmckf_replay_f32.hpp): (8,6), KF / IMCC-KF / RMCKF
+bool replay_f32(int m, int n, int method, int64_t T, hipStream_t s, const uvs::ReplayArgs32 &A);
 // everything else
 void stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *stats, hipStream_t s);
 void debug_math(int which, long long n, const double *x, double *y, hipStream_t s);

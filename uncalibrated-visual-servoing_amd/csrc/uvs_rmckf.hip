@@ -12,6 +12,7 @@
 #include <cstring>
 #include "uvs_rmckf.h"
 #include "launchers.hpp"
+#include "rmckf_replay_f32.hpp"
 
 #ifndef UVS_MCKF_TAPER_PCT               // length of the last segment of an MCKF trial in % of the first (linear in between): 100 / 50 / 25 / 10 % measured
 #define UVS_MCKF_TAPER_PCT 10            // 4.32 / 4.12 / 4.07 / 4.04 ms at 8 segments (unsegmented 4.43), 4.96 / 4.91 / 4.73 / 4.64 on alpha = 1.0 (5.51)
@@ -240,6 +241,19 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
         return check_launch("replay_kernel (careful pass)");
     }
     return UVS_OK;
+}
+
+int uvs_rmckf_replay_f32(const uvs_filter_params *fp, int64_t T, uvs_view_f32 f, uvs_view_f32 dq, uvs_view_f32 x0, uvs_view_f32 x_out,
+                         uvs_view_f32 err_out, int32_t *status, int32_t *k_done, void *stream) {
+    int L = 0;
+    if (int rc = check_params(fp, T, &L)) return rc;
+    if (!f.base || !dq.base || !x0.base) return fail(UVS_ERR_ARG, "%s", "f, dq and x0 views are required");
+    if (fp->method == UVS_METHOD_MCKF) return fail(UVS_ERR_METHOD, "%s", "the single-precision replay runs KF, IMCCKF and GMCKF");
+    auto v = [](const uvs_view_f32 &u) { return uvs::View32{u.base, u.trial_stride, u.step_stride, u.comp_stride}; };
+    uvs::ReplayArgs32 A{*fp, T, v(f), v(dq), v(x0), v(x_out), v(err_out), status, k_done};
+    if (!replay_f32(fp->m, fp->n, fp->method, T, (hipStream_t)stream, A))
+        return fail(UVS_ERR_SHAPE, "%s", "the single-precision replay is instantiated for (m, n) = (8, 6) only");
+    return check_launch("replay_f32_kernel");
 }
 
 int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double *P, const double *f, const double *f_old,

@@ -19,4 +19,5 @@
 #include "tu_careful_b.hip"
 #include "tu_closed_wide.hip"
 #include "tu_replay_tuned.hip"
+#include "tu_replay_f32.hip"
 #include "tu_misc.hip"

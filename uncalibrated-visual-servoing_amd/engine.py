@@ -172,6 +172,23 @@ def replay(fp, f, dq, x0, want=('x', 'err', 'kappa', 'dqcmd'), layout='kct', fin
     return out
 
 
+def replay_f32(fp, f, dq, x0, want=('x', 'err'), layout='kct'):
+    """Single-precision estimator-only replay (uvs_rmckf_replay_f32: a measured lower-precision variant, never the parity path).
+    ``f`` (K + 1 steps), ``dq`` (K steps): fp32 stream tensors in ``layout``; ``x0``: (T, m*n) fp32."""
+    torch = _torch()
+    assert f.dtype == dq.dtype == x0.dtype == torch.float32
+    T, K, m, n = x0.shape[0], fp.steps, fp.m, fp.n
+    dev = x0.device
+    shape = lambda c: {'kct': (K, c, T), 'ktc': (K, T, c), 'tkc': (T, K, c)}[layout]      # noqa: E731
+    out = {'x': torch.empty(shape(m * n), dtype=torch.float32, device=dev) if 'x' in want else None,
+           'err': torch.empty(shape(m), dtype=torch.float32, device=dev) if 'err' in want else None,
+           'status': torch.zeros(T, dtype=torch.int32, device=dev), 'k_done': torch.zeros(T, dtype=torch.int32, device=dev)}
+    rc = _lib.lib().uvs_rmckf_replay_f32(C.byref(fp), T, stream_view(f, layout), stream_view(dq, layout), View(x0.data_ptr(), x0.stride(0), 0, x0.stride(1)),
+                                         stream_view(out['x'], layout), stream_view(out['err'], layout), out['status'].data_ptr(), out['k_done'].data_ptr(), _stream())
+    _lib.check(rc)
+    return out
+
+
 class FilterBank:
     """T estimators whose state (X, P) stays in HBM between ``step`` calls: the drop-in used when the robot is external."""
 
