@@ -583,6 +583,7 @@ def main():
     ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end sweep side object (counter passes: its 49 launches of the headline kernel on other noise would be averaged in)')
     ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'], help='torch.distributed backend (default: nccl = RCCL when every rank has a GPU of its own, gloo when ranks must share cards -- a 1-GPU box)')
+    ap.add_argument('--latency', action='store_true', help='UVS_OPT_LATENCY on the timed launch: the library may use four lanes per filter for shards that do not fill the chip (results differ from the default mapping in the last bits)')
     ap.add_argument('--no-strong-series', action='store_true', help='N > 1, weak: skip the strong-series side measurement')
     ap.add_argument('--no-power', action='store_true', help='skip the power / clock samples under load (about 3 s of extra launches)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
@@ -693,6 +694,8 @@ def main():
     else:
         fp = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
         plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    if args.latency:
+        fp.reserved |= 2                                          # UVS_OPT_LATENCY
     T = hi - lo
     # output buffers are allocated once and reused by every step (engine.closed_loop allocates; here we pre-allocate by hand)
     bufs = {k: engine.alloc_stream(T, K, c, args.layout, dev, zero=True) for k, c in (('x', M * N), ('err', M), ('q', N))}
@@ -777,6 +780,7 @@ def main():
         status_s = torch.zeros(Ts, dtype=torch.int32, device=dev)
         k_done_s = torch.zeros(Ts, dtype=torch.int32, device=dev)
         fp_s = engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+        strong_runs = {}
 
         def launch_s():
             rc = engine.launch_closed_loop(fp_s, plant, Ts, flat(q0_s), engine.stream_view(noise_s, 'kct'), NV, engine.stream_view(bufs_s['x'], 'kct'),
@@ -788,33 +792,37 @@ def main():
             rows = dist.pack_rows(stats_s, status_s)
             return dist.gather_trial_rows(rows if args.backend == 'nccl' else rows.cpu(), len(plan_s))
 
-        for _ in range(max(1, args.warmup)):
-            launch_s()
-            gather_s()
-        barrier()
-        ev_s = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch_s()
-            e1.record()
-            gathered_s = gather_s()
-            ev_s.append((e0, e1))
-        barrier()
-        wall_s = time.perf_counter() - t0
-        k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_s]))
-        w = torch.tensor([wall_s, k_ms, -k_ms], dtype=torch.float64, device=red_dev)
-        td.all_reduce(w, op=td.ReduceOp.MAX)
-        u = torch.tensor([int(k_done_s.sum().item()), int((status_s != 0).sum().item())], dtype=torch.int64, device=red_dev)
-        td.all_reduce(u)
-        assert gathered_s.shape == (len(plan_s), 4)
-        strong_side = {'scaling': 'strong', 'trials_total': len(plan_s), 'trials_rank0': Ts, 'n_gpus': world, 'steps': args.steps,
-                       'ms_per_step': float(w[0]) / args.steps * 1e3, 'value': int(u[0]) * args.steps / float(w[0]), 'unit': 'updates/s',
-                       'kernel_ms_avg_over_ranks': {'max': float(w[1]), 'min': -float(w[2])}, 'failed_trials': int(u[1]),
-                       'lanes_per_filter': args.lanes or engine.supported_lanes(8, 6)[0],
+        for mode, bits in (('default_mapping', 0), ('latency_mapping', 2)):
+            fp_s.reserved = bits
+            for _ in range(max(1, args.warmup)):
+                launch_s()
+                gather_s()
+            barrier()
+            ev_s = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch_s()
+                e1.record()
+                gathered_s = gather_s()
+                ev_s.append((e0, e1))
+            barrier()
+            wall_s = time.perf_counter() - t0
+            k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_s]))
+            w = torch.tensor([wall_s, k_ms, -k_ms], dtype=torch.float64, device=red_dev)
+            td.all_reduce(w, op=td.ReduceOp.MAX)
+            u = torch.tensor([int(k_done_s.sum().item()), int((status_s != 0).sum().item())], dtype=torch.int64, device=red_dev)
+            td.all_reduce(u)
+            assert gathered_s.shape == (len(plan_s), 4)
+            strong_runs[mode] = {'ms_per_step': float(w[0]) / args.steps * 1e3, 'value': int(u[0]) * args.steps / float(w[0]), 'unit': 'updates/s',
+                                 'kernel_ms_avg_over_ranks': {'max': float(w[1]), 'min': -float(w[2])}, 'failed_trials': int(u[1]),
+                                 'lanes_per_filter': int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp_s), C.byref(plant), Ts))}
+        strong_side = {'scaling': 'strong', 'trials_total': len(plan_s), 'trials_rank0': Ts, 'n_gpus': world, 'steps': args.steps, **strong_runs['default_mapping'],
+                       'latency_mapping': strong_runs['latency_mapping'],
                        'note': "north_star's series (one 65 536-trial batch sharded over the ranks + the same all-gather), timed with the same barriers right after the weak "
-                               'run of this job; a side object, never `value`.  A trial is a 299-step serial chain: shards below one round of wavefronts leave SIMDs idle'}
+                               'run of this job; a side object, never `value`.  A trial is a 299-step serial chain: shards below one round of wavefronts leave SIMDs idle.  '
+                               'latency_mapping = the same with UVS_OPT_LATENCY (four lanes per filter where the shard is small; last-bit differences from the default mapping)'}
         del bufs_s, noise_s
 
     if rank == 0:
@@ -872,6 +880,35 @@ def main():
                                'work_items_per_trial': int(uvs_amd.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), T))}
                 noise = noise_head
             fp = fp_head
+        shard_model = None
+        if side_ok and not args.e2e:
+            # What ONE GPU does with the shard a rank of north_star's strong series would own (65 536 / N trials): kernel time per launch on the
+            # first T/N trials of this run's inputs (strided views of the same buffers), default mapping and UVS_OPT_LATENCY.  One-GPU shard
+            # timings -- what the series starts from on every rank -- NOT a scaling curve: no second GPU, no gather.
+            shard_model = {'note': 'one-GPU shard timing, not a scaling curve: kernel ms per launch on the first 65 536 / N trials of the headline inputs; '
+                                   'implied_speedup = (N = 1 kernel time) / (shard kernel time), an upper bound of what N ranks can reach before the gather',
+                           'n1_kernel_ms': avg_ms, 'shards': {}}
+            for n_ranks in (2, 4, 8):
+                Ts = T // n_ranks
+                entry = {'trials': Ts}
+                for mode, bits in (('default_mapping', 0), ('latency_mapping', 2)):
+                    fp_m = type(fp).from_buffer_copy(fp)
+                    fp_m.reserved = bits
+                    ms = []
+                    for i in range(3 + 8):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        rc = engine.launch_closed_loop(fp_m, plant, Ts, flat(q0[:Ts]), engine.stream_view(noise[:, :, :Ts], 'kct'), NV, engine.stream_view(bufs['x'][:, :, :Ts], 'kct'),
+                                                       engine.stream_view(bufs['err'][:, :, :Ts], 'kct'), engine.stream_view(bufs['q'][:, :, :Ts], 'kct'), NV, NV, stats.data_ptr(),
+                                                       status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev)
+                        uvs_amd._lib.check(rc)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if i >= 3:
+                            ms.append(e0.elapsed_time(e1))
+                    entry[mode] = {'kernel_ms': float(np.mean(ms)), 'lanes_per_filter': int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp_m), C.byref(plant), Ts)),
+                                   'implied_speedup': avg_ms / float(np.mean(ms))}
+                shard_model['shards'][f'N={n_ranks}'] = entry
         power = None
         if world == 1 and not args.no_power:                       # after the short side measurements above (seconds of sustained load change what follows)
             power = power_under_load(torch, launch, torch.cuda.current_device())
@@ -905,7 +942,7 @@ def main():
                                     5: 'BASELINE config 5: synthetic 16-feature / 7-DoF (m=32, n=7) linear plant, GMCKF(RMCKF) sigma=10, alpha-stable alpha=1.5, '}[args.config] +
                                    f'{trials_total} trials in total ({T} on rank 0) x {K} updates, ' + ('statistics only (no per-step streams)' if args.stats_only else 'X+err+q logged per step'),
                        'series': series, 'trials_total': trials_total, 'trials_rank0': T, 'trials_per_gpu': T, 'updates_per_trial': K, 'ranks_seen': ranks_seen,
-                       'lanes_per_filter': args.lanes or (8 if args.config == 5 else engine.supported_lanes(M, N)[0]), 'layout': args.layout, 'failed_trials': failed_total},
+                       'lanes_per_filter': int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T)), 'latency_option': bool(args.latency), 'layout': args.layout, 'failed_trials': failed_total},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': (tr_src if traffic is not None else None), 'kernel': 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned UR10 table),2,true>' if (args.config != 5 and args.lanes in (0, 2)) else 'closed_loop kernel, see lanes_per_filter', 'avg_kernel_ms': avg_ms,
                          'algorithmic_bytes_per_update': b_alg, 'updates_per_launch': updates_per_launch,
@@ -913,7 +950,7 @@ def main():
                          'valu': valu, 'power': power},
             'multi_gpu': {'kernel_ms_avg_over_ranks': rank_ms, 'gather_ms': gather_avg, 'gather_inside_timed_region': bool(dist_on), 'backend': args.backend if dist_on else None, 'backend_note': backend_note,
                           'gather_note': 'all_gather of per-trial [ISE, IAE, ITAE, status] rows (32 B/trial); nccl: HIP events on the launch stream, gloo: host clock',
-                          'strong_series': strong_side},
+                          'strong_series': strong_side, 'shard_model': shard_model},
             'cpu_baseline': cpu,
             'replay': replay,
             'config3': side.get('config3'), 'config3_hold': side.get('config3_hold'), 'config5': side.get('config5'), 'other_estimators': others, 'e2e': side.get('e2e'),

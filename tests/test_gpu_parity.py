@@ -859,3 +859,39 @@ def test_alloc_stream_row_pitch_knob(uvs, monkeypatch):
     assert (v.trial_stride, v.step_stride, v.comp_stride) == (1, 3 * 96, 96)
     rec = eng.alloc_stream(64, 5, 3, 'ktc', 'cuda')                               # record layouts are never pitched
     assert rec.is_contiguous() and rec.shape == (5, 64, 3)
+
+
+# ---------------------------------------------------------------------------------------------- UVS_OPT_LATENCY
+def test_latency_option_picks_four_lanes_for_small_batches_and_stays_inside_the_gates(uvs):
+    """the latency mapping (four lanes per filter, for shards that do not fill the chip) is an explicit option because the lane
+    count changes the summation order of the least-squares reductions.  What it picks, that the reference fixture is still met at the same
+    gate, and how far it moves a trial from the default mapping (measured here: last bits, amplified by the closed loop over 299 steps)."""
+    import ctypes as C
+    g = load_golden('closed_gmckf_a1p5')
+    K = len(g['t'])
+    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    lanes = lambda fp, T: int(uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T))      # noqa: E731
+    fp = _fp(uvs, g)
+    assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [2] * 5
+    fp.reserved = 2                                                           # UVS_OPT_LATENCY
+    assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [4, 4, 4, 2, 2]
+    fp_m = _fp(uvs, g); fp_m.method = 3; fp_m.reserved = 2
+    assert lanes(fp_m, 100) == 2                                              # MCKF keeps its two-lane kernel
+    fp4 = _fp(uvs, g, 4); fp4.reserved = 2
+    assert lanes(fp4, 65536) == 4 and lanes(_fp(uvs, g, -2), 100) == 2         # an explicit lanes_per_filter is not overridden
+    T = 200
+    rng = np.random.default_rng(4)
+    q0 = np.tile(g['q_start'], (T, 1)); q0[1:, :2] -= rng.uniform(0, 0.3, (T - 1, 2))
+    noise = np.repeat(g['noise'][:, :, None], T, axis=2); noise[:, :, 1:] = rng.standard_t(3, size=(K, 8, T - 1))
+    outs = []
+    for bits in (0, 2):
+        fp = _fp(uvs, g); fp.reserved = bits
+        outs.append(uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise), want=('x', 'err', 'q')))
+        err, q, X = (outs[-1][k].cpu().numpy()[:, :, 0] for k in ('err', 'q', 'x'))
+        assert rel_err(err, g['err']) <= 1e-8 and rel_err(q, g['q']) <= 1e-8 and rel_err(X[g['X_steps']], g['X']) <= 1e-8
+        assert int(outs[-1]['status'].sum()) == 0
+    a, b = (o['err'].cpu().numpy() for o in outs)
+    dev = np.abs(a - b).max(axis=(0, 1)) / np.abs(a).max(axis=(0, 1))
+    assert not np.array_equal(a, b) and np.median(dev) <= 1e-12 and dev.max() <= 1e-8, (np.median(dev), dev.max())
+    forced = uvs.engine.closed_loop(_fp(uvs, g, 4), plant, _cuda(q0), _cuda(noise), want=('err',))
+    assert np.array_equal(forced['err'].cpu().numpy(), b)                     # the option = lanes_per_filter 4 at this size, bit for bit

@@ -61,6 +61,7 @@ SYMBOLS = {
     'uvs_supported_lanes': (C.c_int, [_I32, _I32, C.POINTER(_I32), _I32]),
     'uvs_rmckf_closed_loop_f64': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64] + [View] * 8 + [_VP] * 3 + [View] * 2 + [_VP]),
     'uvs_rmckf_closed_loop_ws_f64': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64] + [View] * 8 + [_VP] * 3 + [View] * 2 + [_VP, C.c_size_t, _VP]),
+    'uvs_rmckf_closed_loop_lanes': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_closed_loop_segments': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_closed_loop_workspace_bytes': (C.c_size_t, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_replay_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 7 + [_VP] * 2 + [View] * 2 + [_VP]),

@@ -13,7 +13,11 @@ namespace uvs { struct ReplayArgs32; }
 #define UVS_SHAPES_A(X) X(8, 6, 2) X(8, 6, 4)
 #define UVS_SHAPES_B(X)
 #define UVS_TUNED_SHAPES_A(X) X(8, 6, 2)
+#ifdef UVS_QUICK_L4                   // ... plus the four-lane tuned kernel (latency experiments)
+#define UVS_TUNED_SHAPES_B(X) X(8, 6, 4)
+#else
 #define UVS_TUNED_SHAPES_B(X)
+#endif
 #else
 #define UVS_SHAPES_A(X) X(8, 6, 2) X(8, 6, 1) X(8, 6, 4) X(8, 6, 8) X(2, 6, 1)
 #define UVS_SHAPES_B(X) X(6, 6, 2) X(6, 6, 1) X(32, 7, 16) X(32, 7, 32) X(32, 7, 8)

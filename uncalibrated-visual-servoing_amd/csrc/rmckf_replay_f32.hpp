@@ -42,10 +42,14 @@ template <int METHOD, bool XOUT, bool EOUT>
 __global__ __launch_bounds__(64, 2) void replay_f32_kernel(const ReplayArgs32 A) {
     constexpr int M = 8, N = 6, L = 2, RP = M / L / 2, NP = Sym<N>::NP, TPW = 64 / L;     // RP row pairs per lane
     const unsigned lane = threadIdx.x;
-    const int sub = (int)(lane & 1);
+    // blocked lane mapping: lanes 0-31 hold rows 0-3 of 32 consecutive trials, lanes 32-63 rows 4-7 -- every store instruction writes two
+    // whole 128-byte segments (partner lanes side by side would interleave two address streams lane by lane: measured 1.25x slower on the
+    // fp64 replay kernels)
+    const int sub = (int)(lane >> 5);
+    const unsigned tl = lane & 31u;
     const long long wave_first = (long long)blockIdx.x * TPW;
-    const bool valid = wave_first + lane / L < A.T;
-    const long long trial = valid ? wave_first + lane / L : A.T - 1;          // padding lanes shadow the last trial
+    const bool valid = wave_first + tl < A.T;
+    const long long trial = valid ? wave_first + tl : A.T - 1;                // padding lanes shadow the last trial
     const uvs_filter_params &fp = A.fp;
     const int K = fp.steps;
     const int row0 = sub * 2 * RP;                                            // first row of this lane
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(64, 2) void replay_f32_kernel(const ReplayArgs32 A)
             float ss = 0.0f;
 #pragma unroll
             for (int q = 0; q < RP; ++q) ss = fmaf(nu[q].x, nu[q].x, fmaf(nu[q].y, nu[q].y, ss));
-            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 32, 64);
             c_shared = __builtin_amdgcn_exp2f(ss * c_exp2);
         }
         v2f chk = splat(0.0f);                                               // turns NaN as soon as a state entry is non-finite
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(64, 2) void replay_f32_kernel(const ReplayArgs32 A)
         if constexpr (XOUT) px += A.x_out.sk;
         if constexpr (EOUT) pe += A.err_out.sk;
         float bad = chk.x + chk.y;
-        bad += __shfl_xor(bad, 1, 64);
+        bad += __shfl_xor(bad, 32, 64);
         if (alive && !(bad == 0.0f)) {                                       // X non-finite: pinv would raise in the control law (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;

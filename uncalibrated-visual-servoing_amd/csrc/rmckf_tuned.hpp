@@ -553,11 +553,18 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 #ifndef UVS_FAIR_PRIO                   // log2 of the priority turn in shader clocks for the two-wavefront-per-SIMD kernels; experiment builds: 0 = off
 #define UVS_FAIR_PRIO 18
 #endif
+// Wavefronts per SIMD the four-lane kernels are compiled for.  Round 3 shipped 2 (256 registers: the RMCKF instantiation then carried 36-68 B of
+// scratch inside the step loop); at 1 it takes 270 registers, no scratch, and is faster at every size measured (profiles/r04/shard_times.txt:
+// 8 192 trials 0.97 -> 0.90 ms, 16 384: 1.26 -> 1.00, 32 768: 2.06 -> 1.88).  Four lanes per filter are the LATENCY mapping (UVS_OPT_LATENCY):
+// half the trials per wavefront, 14 % fewer instructions per wavefront-step -- the shards of a strong-scaling series that do not fill the chip.
+#ifndef UVS_L4_OCC
+#define UVS_L4_OCC 1
+#endif
 #ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 #define UVS_SHARED_OCC 2
 #endif
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
-__global__ __launch_bounds__(64, (L >= 4 ? 2 : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
+__global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS

@@ -62,6 +62,13 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
     return UVS_OK;
 }
 
+// UVS_OPT_LATENCY: four lanes per filter for a closed-loop batch of the (8,6) shape that four-lane wavefronts still run in one round
+// (1024 SIMDs, one 270-register wavefront each, 16 trials per wavefront); MCKF has no four-lane tuned kernel and keeps two.
+int latency_lanes(const uvs_filter_params *fp, int64_t T, int L) {
+    if (!(fp->reserved & UVS_OPT_LATENCY) || fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF) return L;
+    return (T * 4 + 63) / 64 <= 1024 ? 4 : L;
+}
+
 }  // namespace
 
 extern "C" {
@@ -108,6 +115,13 @@ size_t seg_flag_bytes(int64_t chunks) { return (size_t)((chunks * sizeof(int) + 
 
 int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) { return segments_for(fp, plant, T); }
 
+int uvs_rmckf_closed_loop_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
+    int L = 0;
+    if (!fp || !plant || T <= 0 || check_params(fp, T, &L) != UVS_OK) return 0;
+    if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && plant->kind == UVS_PLANT_LINEAR && !fp->initial_guess && fp->method != UVS_METHOD_MCKF) return 8;
+    return latency_lanes(fp, T, L);
+}
+
 size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
     const int n = segments_for(fp, plant, T);
     if (n <= 1) return 0;
@@ -140,6 +154,7 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
     if (!q_start.base) return fail(UVS_ERR_ARG, "%s", "q_start view is NULL");
     if (!status) return fail(UVS_ERR_ARG, "%s", "status is required (it also carries the suspect marks between the two passes)");
     if (!fp->initial_guess && !x0.base) return fail(UVS_ERR_ARG, "%s", "x0 view is required when initial_guess == 0");
+    L = latency_lanes(fp, T, L);
     uvs::ClosedArgs A;
     A.fp = *fp;
     A.plant = *plant;
