@@ -59,10 +59,13 @@ doc = {'round': rnd, 'workload': 'BASELINE config 2, 65536 trials x 299 updates,
 doc.update(head)
 doc['config3'] = entry('closed_loop_tuned_kernel<8, 6, 2, 5, 2, 2, true>', 524288, U3 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
 doc['config5'] = entry('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 524288, U2 * 2360, 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>')
-doc['other_estimators'] = {name: entry(f'closed_loop_tuned_kernel<8, 6, 2, {code}, 2, 2, true>', 131072, U2 * 560, f'closed_loop_tuned_kernel<8,6,2,{name},DH(axis-aligned),2,true>')
+# (MCKF since round 4: 8 work items per trial chunk, grid 2048 x 8 x 64 -- its hand-over traffic, 141 doubles per lane and segment edge out and back, is part of the counters)
+doc['other_estimators'] = {name: entry(f'closed_loop_tuned_kernel<8, 6, 2, {code}, 2, 2, true>', 1048576 if name == 'MCKF' else 131072, U2 * 560,
+                                       f'closed_loop_tuned_kernel<8,6,2,{name},DH(axis-aligned),2,true>' + (' (8 segments per trial)' if name == 'MCKF' else ''))
                            for name, code in (('KF', 2), ('MCKF', 3), ('IMCCKF', 4))}
 doc['replay'] = {'estimator_only': entry('replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 262144, U2 * 560, 'replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE>'),
                  'estimator_only_records': entry('replay_rows_kernel<8, 6, 4, 5, true, true, false, true, 0>', 262144, U2 * 560, 'replay_rows_kernel<8,6,4,GMCKF,true,true,false,REC>'),
+                 'estimator_only_f32': entry('replay_f32_kernel<5, true, true>', 131072, U2 * 280, 'replay_f32_kernel<GMCKF,true,true> (fp32 measured variant)'),
                  'estimator_and_control_law': entry('replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>', 393216, U2 * 608, 'replay_rows_kernel<8,6,4,GMCKF,true,true,BYWAVE,false,CW=2>')}
 json.dump(doc, open(os.path.join(os.path.dirname(d.rstrip('/')), 'traffic_latest.json'), 'w'), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if not isinstance(v, dict)}, indent=1))
