@@ -81,12 +81,20 @@ def main():
         ref = c_oracle.closed_loop_batch(q0, noise, desired, **kw)
         ref2 = c_oracle.closed_loop_batch(q0 * (1.0 + 1e-14), noise, desired, **kw)
         fp = uvs.engine.make_params(m, n, method, bw, anneal, dt, t_max, gain, desired, m != 32, lane, K, thr, cap)
+        # round 4's launch options: MCKF trials cut into 1-16 segments (tuned two-lane kernel only; others ignore it), the latency mapping,
+        # strict pinv on one case in eight
+        opts = int(rng.integers(1, 17)) << 8 if (method == 'MCKF' and rng.random() < 0.7) else 0
+        if lane == 0 and rng.random() < 0.4:
+            opts |= 2
+        if rng.random() < 0.125:
+            opts |= 1
+        fp.reserved = opts
         nz_dev = torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0) if layout == 'kct' else noise.transpose(1, 0, 2)), device='cuda')
         x0_dev = torch.as_tensor(np.tile(wide['x0'], (T, 1)), device='cuda') if m == 32 else None
         out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), nz_dev, x0_dev, want=('x', 'err', 'q'), layout=layout)
         st, kd = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
         X, E, Q = (uvs.engine.as_tkc(out[k], layout).cpu().numpy() for k in ('x', 'err', 'q'))
-        tag = (case, m, layout, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap)
+        tag = (case, m, layout, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap, opts)
         n_fail += int((ref['status'] == 1).sum())
         if method == 'MCKF':
             n_multi += int((ref['fpi'] >= 2).sum())
