@@ -28,6 +28,7 @@ def test_random_configurations_match_c_oracle(uvs):
     desired = cfg['experiments']['desired_f']
     plant = uvs.SyntheticPlant.ur10(desired).to_struct()
     rng = np.random.default_rng(2026)
+    orng = np.random.default_rng(4)                                           # launch options from their own stream: the cases stay those of round 3
     worst = {}
     for case in range(48):
         method = ['GMCKF', 'KF', 'IMCCKF', 'MCKF'][case % 4]                   # the four estimators (oracle/c restates all of them)
@@ -52,8 +53,8 @@ def test_random_configurations_match_c_oracle(uvs):
         # the latency mapping for the estimators that have a four-lane kernel; the strict-pinv option on every sixth case
         opts = 0
         if method == 'MCKF' and lane in (0, 2):
-            opts |= int(rng.integers(1, 7)) << 8
-        elif lane == 0 and rng.random() < 0.5:
+            opts |= int(orng.integers(1, 7)) << 8
+        elif lane == 0 and orng.random() < 0.5:
             opts |= 2
         if case % 6 == 5:
             opts |= 1
