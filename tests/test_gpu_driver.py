@@ -81,3 +81,21 @@ def test_results_npz_sink(uvs, tmp_path):
     assert np.array_equal(z['status'], np.zeros(6)) and np.array_equal(z['k_done'], np.full(6, 299)) and len(z['t']) == 299
     import json
     assert json.loads(str(z['config']))['estimator']['method'] == 'GMCKF'
+
+
+def test_run_batch_launch_options(uvs):
+    """batch.run_batch(strict_pinv=..., latency=...): the library's option bits reach the launch; a small sweep stays within the oracle
+    gates under either (the options are not config.json keys: the reference's schema is untouched)."""
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = 300
+    base = uvs.batch.run_batch(cfg, cells=[1.5], want=('err',))
+    lat = uvs.batch.run_batch(cfg, cells=[1.5], want=('err',), latency=True)
+    strict = uvs.batch.run_batch(cfg, cells=[1.5], want=('err',), strict_pinv=True)
+    a, b, c = (r.streams['err'].cpu().numpy() for r in (base, lat, strict))
+    scale = np.abs(a).max(axis=(0, 1))
+    assert not np.array_equal(a, b) and np.median(np.abs(a - b).max(axis=(0, 1)) / scale) <= 1e-12      # four lanes: other last bits
+    assert np.median(np.abs(a - c).max(axis=(0, 1)) / scale) <= 1e-12                                   # SVD finish = back substitution to rounding
+    for r in (base, lat, strict):
+        assert int(r.status.sum()) == 0 and r.stats.shape == (300, 3)
+    assert 'strict_pinv' not in cfg and 'latency' not in cfg['experiments'] and 'latency' not in cfg['estimator']

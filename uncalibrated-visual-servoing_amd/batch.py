@@ -129,9 +129,12 @@ def device_noise(cfg, plan, lo, hi, steps, device='cuda'):
 
 
 def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('err',), lanes=0, noise_tensor=None,
-              device='cuda', noise_on_device=True):
+              device='cuda', noise_on_device=True, strict_pinv=False, latency=False):
     """Run this rank's shard of the sweep on its GPU.  Returns a BatchResult whose tensors stay on the device.
-    ``noise_on_device``: generate the measurement noise with the HIP generator (default) or with numpy on the host."""
+    ``noise_on_device``: generate the measurement noise with the HIP generator (default) or with numpy on the host.
+    ``strict_pinv`` / ``latency``: the library's launch options UVS_OPT_STRICT_PINV (numpy's pinv on every control-law solve, slower) and
+    UVS_OPT_LATENCY (four lanes per filter for shards that do not fill the chip: last-bit differences) -- not part of config.json, whose
+    schema stays the reference's."""
     import torch
     cfg = load_config(cfg)
     ex, est = cfg['experiments'], cfg['estimator']
@@ -146,6 +149,7 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
     fp = engine.make_params(m, n, method.name, p.get('kernel_bw', 1.0), p.get('annealing', False), ex['dt'], ex['t_max'],
                             ex['ibvs_gain'], ex['desired_f'], p['initial_guess'], lanes, None, p.get('fpi_threshold', 0.1),
                             p.get('fpi_epoch_max', 1000))
+    fp.reserved = (1 if strict_pinv else 0) | (2 if latency else 0)
     t_log = engine.loop_clock(ex['dt'], ex['t_max'])
     K, Tl = len(t_log), hi - lo
     dev = torch.device(device)
