@@ -59,6 +59,21 @@ def test_fp32_replay_layouts_and_error_returns(uvs):
     a, K = _run(uvs, g, layout='kct')
     b, _ = _run(uvs, g, layout='ktc')
     assert np.array_equal(a['x'].cpu().numpy()[:, :, 3], b['x'].cpu().numpy()[:, 3, :]) and np.array_equal(a['err'].cpu().numpy()[:, :, 3], b['err'].cpu().numpy()[:, 3, :])
+    # distinct trials in full and ragged wavefronts (36 = 32 + 4, 100 = 3 x 32 + 4): the two layouts agree bit for bit, a misplaced lane would show
+    import torch
+    meta, p = g['meta'], g['meta']['params']
+    for T in (36, 100, 4):
+        rng = np.random.default_rng(T)
+        f_seq = np.vstack([g['f_init'][None], g['f']])[:41]
+        f = f_seq[:, :, None] + rng.normal(size=(41, 8, T))
+        dq = g['dq_prev'][:40, :, None] * (1 + 0.1 * rng.normal(size=(1, 1, T)))
+        x0 = np.tile(g['X'][0], (T, 1)) * (1 + 0.01 * rng.normal(size=(T, 1)))
+        fp = uvs.engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'], g['desired'], False, 0, 40)
+        cu = lambda v: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32), device='cuda')      # noqa: E731
+        wide = uvs.engine.replay_f32(fp, cu(f), cu(dq), cu(x0), layout='kct')          # (trial-fastest)
+        narrow = uvs.engine.replay_f32(fp, cu(f.transpose(0, 2, 1)), cu(dq.transpose(0, 2, 1)), cu(x0), layout='ktc')
+        assert torch.equal(wide['x'], narrow['x'].permute(0, 2, 1)) and torch.equal(wide['err'], narrow['err'].permute(0, 2, 1)), T
+        assert len({wide['x'][5, 7, t].item() for t in range(T)}) == T
     V = uvs._lib.NULL_VIEW
     fp = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), steps=3)
     one = uvs._lib.View(1, 0, 0, 0)
