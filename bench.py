@@ -583,7 +583,7 @@ def main():
     ap.add_argument('--e2e', action='store_true', help='only the headline and the end-to-end sweep side object')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end sweep side object (counter passes: its 49 launches of the headline kernel on other noise would be averaged in)')
     ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'], help='torch.distributed backend (default: nccl = RCCL when every rank has a GPU of its own, gloo when ranks must share cards -- a 1-GPU box)')
-    ap.add_argument('--latency', action='store_true', help='UVS_OPT_LATENCY on the timed launch: the library may use four lanes per filter for shards that do not fill the chip (results differ from the default mapping in the last bits)')
+    ap.add_argument('--latency', action='store_true', help='UVS_OPT_LATENCY on the timed launch: plain four-lane kernels for shards that do not fill the chip (a few % faster than the default small-batch kernels; results differ from the default mapping in the last bits)')
     ap.add_argument('--no-strong-series', action='store_true', help='N > 1, weak: skip the strong-series side measurement')
     ap.add_argument('--no-power', action='store_true', help='skip the power / clock samples under load (about 3 s of extra launches)')
     ap.add_argument('--stats-only', action='store_true', help='do not write the per-step X / err / q streams (separate line, B = noise read only)')
@@ -822,7 +822,8 @@ def main():
                        'latency_mapping': strong_runs['latency_mapping'],
                        'note': "north_star's series (one 65 536-trial batch sharded over the ranks + the same all-gather), timed with the same barriers right after the weak "
                                'run of this job; a side object, never `value`.  A trial is a 299-step serial chain: shards below one round of wavefronts leave SIMDs idle.  '
-                               'latency_mapping = the same with UVS_OPT_LATENCY (four lanes per filter where the shard is small; last-bit differences from the default mapping)'}
+                               'The default mapping runs shards up to 16 384 trials on four lanes per filter with the two-lane arithmetic (bit-identical to the 1-GPU sweep); '
+                               'latency_mapping = the same with UVS_OPT_LATENCY (plain four-lane kernels: a few % faster, last-bit differences)'}
         del bufs_s, noise_s
 
     if rank == 0:
@@ -886,14 +887,16 @@ def main():
             # first T/N trials of this run's inputs (strided views of the same buffers), default mapping and UVS_OPT_LATENCY.  One-GPU shard
             # timings -- what the series starts from on every rank -- NOT a scaling curve: no second GPU, no gather.
             shard_model = {'note': 'one-GPU shard timing, not a scaling curve: kernel ms per launch on the first 65 536 / N trials of the headline inputs; '
-                                   'implied_speedup = (N = 1 kernel time) / (shard kernel time), an upper bound of what N ranks can reach before the gather',
+                                   'implied_speedup = (N = 1 kernel time) / (shard kernel time), an upper bound of what N ranks can reach before the gather.  '
+                                   'two_lanes = the headline mapping forced (lanes_per_filter 2); default_mapping = the library choice (up to 16 384 trials four lanes per '
+                                   'filter with the two-lane arithmetic: bit-identical results); latency_mapping = UVS_OPT_LATENCY (plain four-lane kernels, last-bit differences)',
                            'n1_kernel_ms': avg_ms, 'shards': {}}
             for n_ranks in (2, 4, 8):
                 Ts = T // n_ranks
                 entry = {'trials': Ts}
-                for mode, bits in (('default_mapping', 0), ('latency_mapping', 2)):
+                for mode, lanes_m, bits in (('two_lanes', 2, 0), ('default_mapping', 0, 0), ('latency_mapping', 0, 2)):
                     fp_m = type(fp).from_buffer_copy(fp)
-                    fp_m.reserved = bits
+                    fp_m.lanes_per_filter, fp_m.reserved = lanes_m, bits
                     ms = []
                     for i in range(3 + 8):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

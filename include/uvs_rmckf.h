@@ -55,11 +55,12 @@ enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
  *   whose columns are pairwise parallel within ~1e-3 in a cascade (Kahan-like; tests/golden/rankdef_gmckf_kahan_c1000: numpy truncates,
  *   the fast kernels return the plain least-squares command).  Strict mode is several times slower; default off. */
 #define UVS_OPT_STRICT_PINV 1
-/* UVS_OPT_LATENCY: with lanes_per_filter == 0 the closed loop may run a batch that does not fill the chip (at most 16 384 trials of the
- *   (8,6) shape) with four lanes per filter instead of two: half the trials per wavefront, twice the wavefronts, 25 % less time per launch
- *   (8 192 trials: 1.24 -> 0.90 ms on MI355X) -- what a rank of a strong-scaling series (main.py:121-148 split over GPUs) wants.  The lane
- *   count changes the summation order of the least-squares reductions, so results differ from the default mapping in the last bits
- *   (same oracle gates; NOT bit-identical to a run without the option -- which is why it is an option). */
+/* Small batches.  A closed-loop batch of the (8,6) shape that does not fill the chip (at most 16 384 trials; KF / IMCC-KF / GMCKF on the DH
+ *   plant, lanes_per_filter == 0) runs with four lanes per filter instead of two -- half the trials per wavefront, twice the wavefronts, 17-24 %
+ *   less time per launch (8 192 trials: 1.23 -> 0.94 ms on MI355X): what a rank of a strong-scaling split of main.py:121-148 wants.  These
+ *   kernels form every sum in the two-lane kernel's order, so the RESULTS ARE BIT-IDENTICAL to the two-lane kernel's: the choice is invisible.
+ * UVS_OPT_LATENCY: use the plain four-lane kernels there instead (their own summation order: another 3-13 % faster -- 0.88 ms -- and results
+ *   that differ from the default mapping in the last bits; same oracle gates). */
 #define UVS_OPT_LATENCY 2
 
 /* Strided view of a [trial][step][component] array of doubles. */
@@ -160,8 +161,8 @@ int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plan
 size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
 /* Segments per trial the call above would use given a large enough workspace (1 = whole trials); host-side query for logs and benchmarks. */
 int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
-/* Lanes per filter the closed-loop call would use for this (fp, plant, T) -- lanes_per_filter, the shape's default, or the choice of
- * UVS_OPT_LATENCY; 0 when the shape is not instantiated.  Host-side query. */
+/* Lanes per filter the closed-loop call would use for this (fp, plant, T) -- lanes_per_filter, the shape's default, or 4 for a small batch
+ * (see UVS_OPT_LATENCY above); 0 when the shape is not instantiated.  Host-side query. */
 int uvs_rmckf_closed_loop_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
 int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T,
                                  uvs_view q_start, uvs_view noise, uvs_view x0,

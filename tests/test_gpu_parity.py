@@ -872,8 +872,8 @@ def test_latency_option_picks_four_lanes_for_small_batches_and_stays_inside_the_
     plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
     lanes = lambda fp, T: int(uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T))      # noqa: E731
     fp = _fp(uvs, g)
-    assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [2] * 5
-    fp.reserved = 2                                                           # UVS_OPT_LATENCY
+    assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [4, 4, 4, 2, 2]      # by default too: the four-lane kernels with the two-lane bits
+    fp.reserved = 2                                                           # UVS_OPT_LATENCY: the plain four-lane kernels
     assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [4, 4, 4, 2, 2]
     fp_m = _fp(uvs, g); fp_m.method = 3; fp_m.reserved = 2
     assert lanes(fp_m, 100) == 2                                              # MCKF keeps its two-lane kernel
@@ -895,3 +895,40 @@ def test_latency_option_picks_four_lanes_for_small_batches_and_stays_inside_the_
     assert not np.array_equal(a, b) and np.median(dev) <= 1e-12 and dev.max() <= 1e-8, (np.median(dev), dev.max())
     forced = uvs.engine.closed_loop(_fp(uvs, g, 4), plant, _cuda(q0), _cuda(noise), want=('err',))
     assert np.array_equal(forced['err'].cpu().numpy(), b)                     # the option = lanes_per_filter 4 at this size, bit for bit
+
+
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF'])
+def test_small_batches_run_on_four_lanes_with_the_two_lane_bits(uvs, method):
+    """VERDICT r3 #3a, lane-count-invariant arithmetic: up to 16 384 trials the library runs four lanes per filter (EMU2 kernels), which form every
+    sum in the two-lane kernel's order -- so the choice is invisible: every stream, statistic and final state equals the two-lane kernel's
+    (lanes_per_filter = 2) BIT FOR BIT.  Heavy-tailed noise, jittered starts, ragged batch sizes, annealing on and off, both DH code paths
+    (the UR10 table's compile-time zeros and a general table), a non-finite sample that FAILs a trial."""
+    import torch
+    g = load_golden('closed_gmckf_a1p5')
+    K = 120
+    for T, anneal, tilt in ((1, False, False), (23, True, False), (200, False, False), (77, True, True)):
+        rng = np.random.default_rng(T)
+        plant = uvs.SyntheticPlant.ur10(g['desired'])
+        if tilt:
+            plant.alpha = np.asarray(plant.alpha, float).copy()
+            plant.alpha[2] += 0.05                                            # no longer axis-aligned: the general chain code
+        q0 = np.tile(g['q_start'], (T, 1)); q0[:, :3] += rng.uniform(-0.2, 0.1, (T, 3))
+        noise = rng.standard_t(1.5, size=(K, 8, T)) * rng.choice([0.3, 1.0, 4.0], size=T)
+        if T > 50:
+            noise[40, 3, 17] = np.inf
+        outs = []
+        for lanes in (2, 0):
+            fp = uvs.engine.make_params(8, 6, method, 10.0, anneal, 0.05, 15.0, 0.2, g['desired'], True, lanes, K)
+            outs.append(uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise), want=('x', 'err', 'q', 'f', 'dq'), final_state=True))
+        two, four = outs
+        import ctypes as C
+        assert int(uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant.to_struct()), T)) == 4
+        assert torch.equal(two['status'], four['status']) and torch.equal(two['k_done'], four['k_done'])
+        live = torch.arange(K, device='cuda')[:, None, None] < two['k_done'][None, None, :]
+        for key in ('x', 'err', 'q', 'f', 'dq'):
+            assert torch.equal(torch.where(live, two[key], 0.0).view(torch.int64), torch.where(live, four[key], 0.0).view(torch.int64)), (key, T)
+        ok = two['status'] == 0
+        for key in ('stats', 'x_final', 'p_final'):
+            assert torch.equal(two[key][ok].view(torch.int64), four[key][ok].view(torch.int64)), (key, T)
+        if T > 50:
+            assert int(two['status'][17]) == 1 and int(two['k_done'][17]) == 40

@@ -296,11 +296,19 @@ def test_default_kernels_have_no_scratch():
     for method in (2, 3, 4, 5):                                              # KF, MCKF, IMCCKF, GMCKF
         for plant in (0, 1, 2):                                              # DH, linear, DH with the UR10-like table's compile-time zeros
             for xout in ('true', 'false'):
-                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}>']
+                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false>']
                 assert r['scratch'] == 0 and r['vgpr'] <= 512, (method, plant, xout, r)
                 # KF / IMCC-KF keep one covariance block per lane and must fit two wavefronts per SIMD (256 registers, 8 x 19 KB of LDS per CU)
                 if method in (2, 4):
                     assert r['vgpr'] <= 256 and r['lds'] <= 20480, (method, r)
+    # the small-batch kernels: four lanes per filter with the two-lane kernel's bits (EMU2, the default up to 16 384 trials) and the plain
+    # four-lane kernels of UVS_OPT_LATENCY -- one wavefront per SIMD, no scratch (round 3's four-lane RMCKF carried 36-68 B at two per SIMD)
+    for method in (2, 4, 5):
+        for plant in (0, 2):
+            for xout in ('true', 'false'):
+                assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, {plant}, 2, {xout}, true>']['scratch'] == 0
+        for xout in ('true', 'false'):
+            assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, 0, 2, {xout}, false>']['scratch'] == 0
     for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true>',
                  'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
         assert k[name]['scratch'] == 0, (name, k[name])

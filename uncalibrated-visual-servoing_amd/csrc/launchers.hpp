@@ -25,6 +25,9 @@ namespace uvs { struct ReplayArgs32; }
 #define UVS_TUNED_SHAPES_B(X) X(8, 6, 1) X(8, 6, 4)
 #endif
 #define UVS_SHAPES(X) UVS_SHAPES_A(X) UVS_SHAPES_B(X)
+#if !defined(UVS_QUICK) || defined(UVS_QUICK_L4)
+#define UVS_HAVE_EMU2 1               // the four-lane kernels with the two-lane kernel's bits are in this build (tu_closed_tuned_b.hip)
+#endif
 // one careful (numpy-pinv) instantiation of the generic closed-loop / replay kernels per shape: the second pass over suspect trials
 #ifdef UVS_QUICK
 #define UVS_CAREFUL_SHAPES_A(X) X(8, 6, 4)
@@ -42,6 +45,8 @@ inline dim3 grid_for(int64_t T, int L) { return dim3((unsigned)((T * L + 63) / 6
 // tuned closed loop (rmckf_tuned.hpp): method in {KF, IMCCKF, GMCKF}
 bool closed_tuned_a(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 bool closed_tuned_b(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
+// four lanes per filter with the two-lane kernel's bits (EMU2): (8,6), DH plant, KF / IMCC-KF / RMCKF -- the automatic choice for batches that do not fill the chip
+bool closed_tuned_emu2(int m, int n, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 // tuned wide-shape closed loop (rmckf_wide.hpp): (32,7), lanes_per_filter = 8 (the default of that shape for the closed loop)
 bool closed_wide(int m, int n, int L, int method, bool linear, bool xo, int64_t T, hipStream_t s, const uvs::ClosedArgs &A);
 // generic templates (rmckf_generic.hpp)

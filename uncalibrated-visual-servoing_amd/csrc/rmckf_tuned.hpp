@@ -519,6 +519,117 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     return lstsq_tall_tuned<M, N, L>(a, sub, sol, unused);
 }
 
+// ------------------------------------------------------------------------------------------------ four lanes, the two-lane kernel's bits
+// EMU2: a filter on the four lanes of a quad that reproduces the TWO-lane kernel's arithmetic bit for bit, so that the launcher may pick it for
+// batches that do not fill the chip without changing a single result (an N-GPU sweep returns the bits of the 1-GPU sweep).  Quad lane
+// `sub` = p + 2 h: p is the parity the two-lane kernel's lane has (u rows / v rows, kinematic half chain), h says which half of that lane's
+// four local rows this lane holds (two-lane local row R2 = 2 h + r, global row 2 R2 + p).  Everything lane-local is the two-lane code on half
+// the rows; every sum the two-lane kernel forms as a sequential chain over its four local rows is formed here in the same order -- h = 0 starts
+// it, hands it to h = 1 (quad_perm [0,1,0,1]), which finishes it; the pair sum across p and a broadcast back (quad_perm [2,3,2,3]) follow.
+constexpr int kQuadFromLow = 0x44;       // quad_perm [0,1,0,1]: value of the h = 0 lane of the same parity
+constexpr int kQuadFromHigh = 0xEE;      // quad_perm [2,3,2,3]: value of the h = 1 lane of the same parity
+// total = (chain finished on the h = 1 lanes) summed over the two parities, delivered to all four lanes
+UVS_DEV double emu2_finish(double chain_on_high) {
+    const double t = chain_on_high + dpp_quad<kSwapPair>(chain_on_high);
+    return dpp_quad<kQuadFromHigh>(t);
+}
+// Householder least squares of the 8 x (6 + 1) panel: a[r][.] is the lane's local row r (two-lane local row 2 h + r).  Same operations on the
+// same values in the same order as lstsq_tall_tuned<8, 6, 2>; see there for the algorithm and for what `nonfinite` and the return value mean.
+template <int M, int N>
+UVS_DEV bool lstsq_tall_emu2(double (&a)[2][N + 1], int sub, double (&sol)[N], bool &nonfinite) {
+    static_assert(M == 8, "EMU2 splits the four local rows of a two-lane filter over two lanes");
+    const int p = sub & 1;
+    const bool high = sub & 2;
+    double rdiag[N];
+    double rmax_lo = 0.0, rmax_hi = 0.0;                            // largest |R_cj| of the rows finished on the h = 0 / h = 1 lanes
+    Spread spread;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const int m = c / 2, owner = c % 2;                         // two-lane local row of the pivot, parity that owns it
+        const int hm = m / 2, rm = m % 2;                           // ... which lives on the h = hm lanes at local row rm
+        const bool is_piv = (p == owner), is_below = (p > owner);
+        // squared norm of the column below the pivot: two-lane order = (row m if below the pivot), rows m + 1 .. 3 of the lane, then the other parity
+        double sig;
+        {
+            const double seed = is_below ? a[rm][c] * a[rm][c] : 0.0;
+            if (hm == 0) {
+                double s0 = seed;
+                if (rm == 0) s0 = fma(a[1][c], a[1][c], s0);
+                double s1 = dpp_quad<kQuadFromLow>(s0);
+                s1 = fma(a[0][c], a[0][c], s1);
+                s1 = fma(a[1][c], a[1][c], s1);
+                sig = emu2_finish(s1);
+            } else {
+                double s1 = seed;
+                if (rm == 0) s1 = fma(a[1][c], a[1][c], s1);
+                sig = emu2_finish(s1);
+            }
+        }
+        const double piv = pair_from_dyn<4>(a[rm][c], owner + 2 * hm);
+        const double n2 = fma(piv, piv, sig);
+        spread.add(n2);
+        double nrm, rn;
+        fast_sqrt_rsqrt_1(n2, nrm, rn);
+        const double vp = piv + copysign(nrm, piv);
+        const double tau = rn * fast_rcp_1(fabs(vp));
+        const double vm = is_piv ? vp : (is_below ? a[rm][c] : 0.0);     // entry of the Householder vector in two-lane local row m
+        // this lane's entries of the vector in its local rows 0, 1: the h = hm lanes hold row m (and, below it, ordinary rows); the h = 1 lanes hold only
+        // ordinary rows while hm = 0; the h = 0 lanes are finished once hm = 1 (zero: they neither contribute nor change)
+        double v[2];
+        if (hm == 0) {
+            v[0] = high ? a[0][c] : (rm == 0 ? vm : 0.0);
+            v[1] = high ? a[1][c] : (rm == 1 ? vm : a[1][c]);
+        } else {
+            v[0] = high ? (rm == 0 ? vm : 0.0) : 0.0;
+            v[1] = high ? (rm == 1 ? vm : a[1][c]) : 0.0;
+        }
+#pragma unroll
+        for (int j = c + 1; j <= N; ++j) {
+            double d1;
+            if (hm == 0) {
+                double d0 = v[rm] * a[rm][j];
+                if (rm == 0) d0 = fma(v[1], a[1][j], d0);
+                d1 = dpp_quad<kQuadFromLow>(d0);
+                d1 = fma(v[0], a[0][j], d1);
+                d1 = fma(v[1], a[1][j], d1);
+            } else {
+                d1 = v[rm] * a[rm][j];
+                if (rm == 0) d1 = fma(v[1], a[1][j], d1);
+            }
+            const double d = emu2_finish(d1) * tau;
+            // rows that are finished stay untouched, as in the two-lane code (a product with a zero entry could still flip the sign of a zero)
+            const double u0 = fma(-d, v[0], a[0][j]), u1 = fma(-d, v[1], a[1][j]);
+            if (hm == 0) {
+                a[0][j] = (rm == 1) ? (high ? u0 : a[0][j]) : u0;
+                a[1][j] = u1;
+            } else {
+                a[0][j] = (rm == 0) ? (high ? u0 : a[0][j]) : a[0][j];
+                a[1][j] = high ? u1 : a[1][j];
+            }
+#ifndef UVS_NO_ENTRY_WATCH
+            if (j < N) { if (hm == 0) rmax_lo = fmax(rmax_lo, fabs(a[rm][j])); else rmax_hi = fmax(rmax_hi, fabs(a[rm][j])); }
+#endif
+        }
+        rdiag[c] = -copysign(rn, piv);
+    }
+    {   // the two-lane kernel's watch: rows 2 m + {0, 1} for every column -- here the h = hm lanes of both parities
+        double rmax = fmax(dpp_quad<kQuadFromLow>(rmax_lo), dpp_quad<kQuadFromHigh>(rmax_hi));
+        rmax = fmax(rmax, dpp_quad<kSwapPair>(rmax));
+        spread.add_largest(rmax);
+    }
+#pragma unroll
+    for (int c = N - 1; c >= 0; --c) {
+        const int m = c / 2, owner = c % 2, hm = m / 2, rm = m % 2;
+        double rhs = a[rm][N];
+#pragma unroll
+        for (int j = c + 1; j < N; ++j) rhs = fma(-a[rm][j], sol[j], rhs);
+        rhs = pair_from_dyn<4>(rhs, owner + 2 * hm);
+        sol[c] = rhs * rdiag[c];
+    }
+    nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
+    return spread.suspect() || spread.hi == 0x7ff00000u;
+}
+
 // Internal plant kind (not part of the ABI): UVS_PLANT_DH_PINHOLE whose DH table has, in either half of a six-link chain, alpha = -pi/2 on
 // the first link and alpha = 0 on the last (the UR10: -pi/2, 0, 0 | -pi/2, pi/2, 0).  The launcher selects it when the table says so.
 constexpr int kPlantDhAxisAligned = 2;
@@ -563,7 +674,7 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 #ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 #define UVS_SHARED_OCC 2
 #endif
-template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT>
+template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false>
 __global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
@@ -576,9 +687,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool DH = (PLANT == UVS_PLANT_DH_PINHOLE || PLANT == kPlantDhAxisAligned);
     constexpr bool AXIS = (PLANT == kPlantDhAxisAligned);
-    static_assert(!AXIS || (L == 2 && N == 6), "the axis-aligned chain is written for three links per lane");
-    constexpr bool SPLIT = DH && (L == 2 || L == 4) && (N % (L == 2 ? 2 : 3) == 0);
-    constexpr int G = SPLIT ? (L == 2 ? 2 : 3) : 1;
+    static_assert(!EMU2 || (L == 4 && M == 8 && N == 6 && METHOD != UVS_METHOD_MCKF), "EMU2: the (8,6) two-lane arithmetic on the four lanes of a quad");
+    constexpr bool HALVES = (L == 2 || EMU2);                      // the kinematic chain in two halves of three links (else three groups of two)
+    static_assert(!AXIS || (HALVES && N == 6), "the axis-aligned chain is written for three links per lane");
+    constexpr bool SPLIT = DH && (L == 2 || L == 4) && (N % (HALVES ? 2 : 3) == 0);
+    constexpr int G = SPLIT ? (HALVES ? 2 : 3) : 1;
     constexpr int JG = N / G;                                      // joints tracked by this lane
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;       // rows per lane, packed block size, trials per wavefront
     static_assert(PV >= 0 && PV <= R, "PV counts covariance blocks");
@@ -601,7 +714,16 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #endif
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
-    const int grp = SPLIT ? (sub < G ? sub : G - 1) : 0;           // with L = 4 the fourth lane mirrors group 2
+    const int grp = SPLIT ? (EMU2 ? (sub & 1) : (sub < G ? sub : G - 1)) : 0;   // with L = 4 the fourth lane mirrors group 2 (EMU2: group = parity)
+    // rows of a lane: local row r is global row r * RS + rb (interleaved over the L lanes; EMU2: 4 h + 2 r + p, the two-lane kernel's rows 2 (2 h + r) + p)
+    constexpr int RS = EMU2 ? 2 : L;
+    const int rb = EMU2 ? 4 * (sub >> 1) + (sub & 1) : sub;
+    auto own_row = [&](auto &&at, int r) {                         // at(global row) for this lane's local row r, without a variably indexed access
+        double cand[L];
+#pragma unroll
+        for (int u = 0; u < L; ++u) cand[u] = at(r * RS + (EMU2 ? 4 * (u >> 1) + (u & 1) : u));
+        return pick_sub<L>(cand, sub);
+    };
 #ifdef UVS_PERSISTENT                   // experiment build: a persistent grid (as many wavefronts as the chip holds) pulling 64 / L-trial work
     for (;;) {                          // items from a global atomic counter instead of one workgroup per item (measured, not shipped)
         unsigned item_ = 0;
@@ -678,10 +800,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     }
 
     // per-lane stream cursors (advance by the step stride once per step; components are reached by adding the uniform stride)
-    const double *pn = A.noise.p ? A.noise.at(trial, 0, sub) : nullptr;
-    double *px = A.x_out.p ? A.x_out.at(trial, 0, sub * N) : nullptr;
-    double *pe = A.err_out.p ? A.err_out.at(trial, 0, sub) : nullptr;
-    double *pf = A.f_out.p ? A.f_out.at(trial, 0, sub) : nullptr;
+    const double *pn = A.noise.p ? A.noise.at(trial, 0, rb) : nullptr;
+    double *px = A.x_out.p ? A.x_out.at(trial, 0, rb * N) : nullptr;
+    double *pe = A.err_out.p ? A.err_out.at(trial, 0, rb) : nullptr;
+    double *pf = A.f_out.p ? A.f_out.at(trial, 0, rb) : nullptr;
     double *pq = A.q_out.p ? A.q_out.at(trial, 0, grp * JG) : nullptr;
     double *pd = A.dq_out.p ? A.dq_out.at(trial, 0, grp * JG) : nullptr;
     // Component addresses are formed from the step cursor with the whole index expression (cursor + (row, column) * comp_stride), not by
@@ -715,7 +837,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true, flagged = false;                          // flagged: a rank-deficient Jacobian was seen -> careful second pass
 #pragma unroll
-    for (int r = 0; r < R; ++r) des[r] = pick_sub<L>(&fp.desired[r * L], sub);
+    for (int r = 0; r < R; ++r) des[r] = own_row([&](int row) { return fp.desired[row]; }, r);
     // The state of a trial chunk between two of its segments, [field][lane] in the workspace (seg_state_doubles per lane).
     auto seg_state = [&](auto saving) {
         constexpr bool SAVE = decltype(saving)::value;
@@ -784,13 +906,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             initial_guess<M, N, 1>(A.plant, q_all, 0, xa, fa);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                f_prev[r] = pick_sub<L>(&fa[r * L], sub);
+                f_prev[r] = own_row([&](int row) { return fa[row]; }, r);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    double cand[L];
-#pragma unroll
-                    for (int u = 0; u < L; ++u) cand[u] = xa[r * L + u][j];
-                    x0[r][j] = pick_sub<L>(cand, sub);
+                    x0[r][j] = own_row([&](int row) { return xa[row][j]; }, r);
                 }
             }
         } else {
@@ -798,7 +917,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             for (int r = 0; r < R; ++r) {
                 f_prev[r] = 0.0;                                   // f = zeros(m) (experiment.py:56)
 #pragma unroll
-                for (int j = 0; j < N; ++j) x0[r][j] = *A.x0.at(trial, 0, (r * L + sub) * N + j);
+                for (int j = 0; j < N; ++j) x0[r][j] = *A.x0.at(trial, 0, (r * RS + rb) * N + j);
             }
         }
 #pragma unroll
@@ -840,7 +959,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     }
     if (on_noise && k_begin < K) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) nz_next[r] = pn[r * L * A.noise.sc];
+        for (int r = 0; r < R; ++r) nz_next[r] = pn[r * RS * A.noise.sc];
         pn += A.noise.sk;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
@@ -879,7 +998,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int r = 0; r < R; ++r) nz[r] = nz_next[r];
         if (on_noise && k + 1 < K) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) nz_next[r] = pn[r * L * A.noise.sc];
+            for (int r = 0; r < R; ++r) nz_next[r] = pn[r * RS * A.noise.sc];
             pn += A.noise.sk;
         }
         // ---- plant: noise-free features of this lane's rows
@@ -894,7 +1013,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int row = r * L + sub;
+                const int row = r * RS + rb;
                 double acc = A.plant.lin_f0[row];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc = fma(A.plant.lin_jacobian[row * N + j], q[j] - A.plant.lin_q0[j], acc);
@@ -1050,6 +1169,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if constexpr (L == 2) w[c] = lds_c[PC::kPoint + 3 * r + c];
+                        else if constexpr (EMU2) w[c] = (sub & 2) ? lds_c[PC::kPoint + 3 * (2 + r) + c] : lds_c[PC::kPoint + 3 * r + c];   // row 4 h + 2 r + p: point 2 h + r
                         else w[c] = (sub & 2) ? lds_c[PC::kPoint + 3 * (2 * r + 1) + c] : lds_c[PC::kPoint + 3 * (2 * r) + c];
                     }
                     const double dx = w[0] - vp[0], dy = w[1] - vp[1], dz = w[2] - vp[2];
@@ -1068,16 +1188,25 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
         double c_shared = 1.0;
         if constexpr (METHOD == UVS_METHOD_IMCCKF) {             // one weight for the whole filter: G(||Z - H X||) (experiment.py:258-261)
-            double ss = 0.0;
+            double ss = 0.0, nu_im[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double pred = 0.0;
 #pragma unroll
                 for (int j = 0; j < N; ++j) pred = fma(XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane], dq[j], pred);
                 const double nu = (z[r] + nz[r] - f_prev[r]) - pred;
+                nu_im[r] = nu;
                 ss = fma(nu, nu, ss);
             }
-            c_shared = exp_nonpos(pair_sum<L>(ss) * neg_half_inv_s2);   // sqrt(.)**2 of the reference folded: G(n) = exp(-n^2 / (2 sigma^2))
+            if constexpr (EMU2) {                                // the two-lane chain over four local rows: h = 0 starts it, h = 1 finishes it
+                double s1 = dpp_quad<kQuadFromLow>(ss);
+#pragma unroll
+                for (int r = 0; r < R; ++r) s1 = fma(nu_im[r], nu_im[r], s1);
+                ss = emu2_finish(s1);
+            } else {
+                ss = pair_sum<L>(ss);
+            }
+            c_shared = exp_nonpos(ss * neg_half_inv_s2);         // sqrt(.)**2 of the reference folded: G(n) = exp(-n^2 / (2 sigma^2))
         }
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
@@ -1130,7 +1259,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #endif
                 {
 #pragma unroll
-                    for (int j = 0; j < N; ++j) px[(r * L * N + j) * A.x_out.sc] = x[j];
+                    for (int j = 0; j < N; ++j) px[(r * RS * N + j) * A.x_out.sc] = x[j];
                 }
             }
             if constexpr (!SHARED_P) {
@@ -1265,8 +1394,9 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #else
             // X non-finite: pinv would raise (experiment.py:313-316).  The verdict comes out of the QR's column norms (lstsq_tall_tuned);
             // the per-entry probe `chk` that the rows accumulate is dead code in this kernel.
-            bool nonfinite;
-            const bool suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite);
+            bool nonfinite, suspect;
+            if constexpr (EMU2) suspect = lstsq_tall_emu2<M, N>(panel, sub, sol, nonfinite);
+            else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite);
 #endif
             if constexpr (METHOD == UVS_METHOD_MCKF) nonfinite |= fpi.poison && !fpi.skip;      // the reference's NaN state after a subnormal weight
             if (alive && nonfinite) {
@@ -1284,12 +1414,12 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         // ---- logs and statistics
         if (on_err) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) pe[r * L * A.err_out.sc] = err[r];
+            for (int r = 0; r < R; ++r) pe[r * RS * A.err_out.sc] = err[r];
             pe += UVS_SK(A.err_out.sk);
         }
         if (on_f) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) pf[r * L * A.f_out.sc] = f_prev[r];
+            for (int r = 0; r < R; ++r) pf[r * RS * A.f_out.sc] = f_prev[r];
             pf += A.f_out.sk;
         }
         double dq_own[JG];                                       // the command for this lane's joints
@@ -1396,8 +1526,18 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             s2[c] = fma(v, v, s2[c]);
         }
     }
+    if constexpr (EMU2) {                                        // the two-lane chain over four local rows, then the pair sum
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
+        for (int c = 0; c < 3; ++c) {
+            double s1 = dpp_quad<kQuadFromLow>(s2[c]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const double v = lds_acc[c * R + r][lane]; s1 = fma(v, v, s1); }
+            s2[c] = emu2_finish(s1);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
+    }
     if (!valid) UVS_ITEM_END;
     if (sub == 0) {
 #ifdef UVS_WAVE_TIMES
@@ -1429,7 +1569,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                *A.x_final.at(trial, 0, (r * L + sub) * N + j) = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
+                *A.x_final.at(trial, 0, (r * RS + rb) * N + j) = XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane];
     }
     if (A.p_final.on()) {
 #pragma unroll
@@ -1438,7 +1578,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             for (int l = 0; l < N; ++l)
 #pragma unroll
                 for (int j = 0; j < N; ++j)
-                    *A.p_final.at(trial, 0, ((r * L + sub) * N + l) * N + j) =
+                    *A.p_final.at(trial, 0, ((r * RS + rb) * N + l) * N + j) =
                         SHARED_P ? p[0][Sym<N>::at(l, j)]
                                  : (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }

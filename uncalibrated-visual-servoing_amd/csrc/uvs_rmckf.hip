@@ -62,11 +62,18 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
     return UVS_OK;
 }
 
-// UVS_OPT_LATENCY: four lanes per filter for a closed-loop batch of the (8,6) shape that four-lane wavefronts still run in one round
-// (1024 SIMDs, one 270-register wavefront each, 16 trials per wavefront); MCKF has no four-lane tuned kernel and keeps two.
-int latency_lanes(const uvs_filter_params *fp, int64_t T, int L) {
-    if (!(fp->reserved & UVS_OPT_LATENCY) || fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF) return L;
-    return (T * 4 + 63) / 64 <= 1024 ? 4 : L;
+// Four lanes per filter for a closed-loop batch of the (8,6) shape that four-lane wavefronts still run in one round (1024 SIMDs, one wavefront
+// each, 16 trials per wavefront): half the trials per wavefront, a shorter step, 20-28 % less time per launch.  By default
+// -- lanes_per_filter == 0, KF / IMCC-KF / RMCKF on the DH plant -- the EMU2 kernels, which reproduce the two-lane arithmetic bit for bit, so
+// the choice is invisible in the results; with UVS_OPT_LATENCY the plain four-lane kernels (3-7 % faster still, last-bit differences).  MCKF has
+// no four-lane tuned kernel and keeps two lanes.  Returns 0 = no change, 4 = plain four lanes, -4 = four lanes with the two-lane bits.
+int small_batch_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
+    if (fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF || (T * 4 + 63) / 64 > 1024) return 0;
+    if (fp->reserved & UVS_OPT_LATENCY) return 4;
+#ifdef UVS_HAVE_EMU2
+    if (plant->kind == UVS_PLANT_DH_PINHOLE && !(fp->reserved & UVS_OPT_STRICT_PINV)) return -4;
+#endif
+    return 0;
 }
 
 }  // namespace
@@ -119,7 +126,7 @@ int uvs_rmckf_closed_loop_lanes(const uvs_filter_params *fp, const uvs_plant *pl
     int L = 0;
     if (!fp || !plant || T <= 0 || check_params(fp, T, &L) != UVS_OK) return 0;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && plant->kind == UVS_PLANT_LINEAR && !fp->initial_guess && fp->method != UVS_METHOD_MCKF) return 8;
-    return latency_lanes(fp, T, L);
+    return small_batch_lanes(fp, plant, T) ? 4 : L;
 }
 
 size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
@@ -154,7 +161,8 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
     if (!q_start.base) return fail(UVS_ERR_ARG, "%s", "q_start view is NULL");
     if (!status) return fail(UVS_ERR_ARG, "%s", "status is required (it also carries the suspect marks between the two passes)");
     if (!fp->initial_guess && !x0.base) return fail(UVS_ERR_ARG, "%s", "x0 view is required when initial_guess == 0");
-    L = latency_lanes(fp, T, L);
+    const int small = small_batch_lanes(fp, plant, T);
+    if (small == 4) L = 4;
     uvs::ClosedArgs A;
     A.fp = *fp;
     A.plant = *plant;
@@ -199,6 +207,9 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
         if (hipMemsetD32Async((hipDeviceptr_t)status, uvs::UVS_STATUS_SUSPECT, (size_t)T, s) != hipSuccess) return check_launch("strict pinv: marking the trials");
         launched = true;
     }
+#ifdef UVS_HAVE_EMU2
+    if (!launched && tuned_ok && small == -4) launched = closed_tuned_emu2(fp->m, fp->n, fp->method, linear, xo, T, s, A);
+#endif
     if (!launched && tuned_ok) launched = closed_wide(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched && tuned_ok) launched = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
     if (!launched) launched = closed_generic_a(fp->m, fp->n, L, fp->method, T, s, A) || closed_generic_b(fp->m, fp->n, L, fp->method, T, s, A);
