@@ -530,8 +530,9 @@ constexpr int kQuadFromLow = 0x44;       // quad_perm [0,1,0,1]: value of the h 
 constexpr int kQuadFromHigh = 0xEE;      // quad_perm [2,3,2,3]: value of the h = 1 lane of the same parity
 // total = (chain finished on the h = 1 lanes) summed over the two parities, delivered to all four lanes
 UVS_DEV double emu2_finish(double chain_on_high) {
-    const double t = chain_on_high + dpp_quad<kSwapPair>(chain_on_high);
-    return dpp_quad<kQuadFromHigh>(t);
+    // both parities' finished chains fetched independently (quad_perm [2,2,2,2] and [3,3,3,3]) and added: the two-lane kernel's own + partner's,
+    // commutative, so every lane holds its bits -- one cross-lane hop on the critical path instead of two (add on the h = 1 lanes, then broadcast)
+    return dpp_quad<0xAA>(chain_on_high) + dpp_quad<0xFF>(chain_on_high);
 }
 // Householder least squares of the 8 x (6 + 1) panel: a[r][.] is the lane's local row r (two-lane local row 2 h + r).  Same operations on the
 // same values in the same order as lstsq_tall_tuned<8, 6, 2>; see there for the algorithm and for what `nonfinite` and the return value mean.
