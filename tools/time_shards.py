@@ -33,5 +33,8 @@ for T in [int(t) for t in args.trials.split(',')]:
             torch.cuda.synchronize()
             if i >= 3:
                 ms.append(out['events'][0].elapsed_time(out['events'][1]))
-        print(f'trials {T:6d} lanes {L}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f}); wavefronts {T * L // 64}; failed {int((out["status"] != 0).sum())}', flush=True)
+        import ctypes as C
+        used = int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T))
+        print(f'trials {T:6d} lanes {L} (kernel: {used} per filter{", two-lane bits" if L == 0 and used == 4 else ""}): {np.mean(ms):.3f} ms (min {np.min(ms):.3f}); '
+              f'wavefronts {T * used // 64}; failed {int((out["status"] != 0).sum())}', flush=True)
     del noise
