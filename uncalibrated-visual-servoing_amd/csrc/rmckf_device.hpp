@@ -429,7 +429,7 @@ struct Rows {
 //     WHAT NO SUCH WATCH SEES: a factor with every entry of ordinary size whose inverse still explodes (Kahan-like: unit diagonal, all
 //     off-diagonals -1000, condition 3e18; fixture rankdef_gmckf_kahan).  The fast kernels return the plain least-squares command there,
 //     numpy truncates.  It takes columns that are pairwise parallel within 1e-3 in a fixed cascade; callers who must have numpy's answer
-//     there too set UVS_OPT_STRICT_PINV in fp->reserved, which sends EVERY trial through the careful kernels below (several times slower).
+//     there too set UVS_OPT_STRICT_PINV in fp->reserved, which sends EVERY trial through the careful kernels below (about 16 times slower: the generic kernel with an SVD on every solve).
 //     Normal-equation solvers (wide kernel, control wavefronts of the replay) mark at a spread of 2^20 already and are accurate to ~6e-9
 //     in the command up to cond 1e6;
 //   * suspect trials are re-run from their first step by the `careful` instantiation of the generic kernels, launched right behind
