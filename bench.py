@@ -507,8 +507,14 @@ def scrubbed_env(env=None):
     through an inherited tool library and then execs (a `#!/usr/bin/env` script does) is the hop this pool forbids."""
     env = dict(os.environ if env is None else env)
     for k in list(env):
-        if k == 'LD_PRELOAD' or k.startswith(PROFILER_ENV_PREFIXES):
+        if k.startswith(PROFILER_ENV_PREFIXES):
             env.pop(k)
+    if 'LD_PRELOAD' in env:                                       # only the profiler's entries go; whatever else the host preloads stays
+        keep = [e for e in env['LD_PRELOAD'].replace(' ', ':').split(':') if e and 'rocprof' not in e.lower()]
+        if keep:
+            env['LD_PRELOAD'] = ':'.join(keep)
+        else:
+            env.pop('LD_PRELOAD')
     return env
 
 

@@ -52,6 +52,8 @@ def test_profiler_environment_is_detected_and_scrubbed():
     assert bench.under_profiler(prof) and bench.under_profiler({'ROCPROF_COUNTERS': 'pmc: SQ_WAVES'})
     assert bench.under_profiler({'LD_PRELOAD': '/x/librocprofiler-sdk-tool.so.1'}) and not bench.under_profiler({'LD_PRELOAD': '/x/libjemalloc.so'})
     assert bench.scrubbed_env(prof) == plain
+    mixed = dict(plain, LD_PRELOAD='/usr/lib/libguard.so:/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so', ROCP_TOOL_LIBRARIES='x')
+    assert bench.scrubbed_env(mixed) == dict(plain, LD_PRELOAD='/usr/lib/libguard.so')       # only the profiler's entry goes
 
 
 def test_plain_gpus_n_starts_its_own_ranks_and_a_failing_rank_is_loud(tmp_path):
