@@ -932,3 +932,35 @@ def test_small_batches_run_on_four_lanes_with_the_two_lane_bits(uvs, method):
             assert torch.equal(two[key][ok].view(torch.int64), four[key][ok].view(torch.int64)), (key, T)
         if T > 50:
             assert int(two['status'][17]) == 1 and int(two['k_done'][17]) == 40
+
+
+@pytest.mark.parametrize('T', [8192, 16384])
+def test_small_batch_kernels_at_the_shard_sizes_of_the_strong_series(uvs, T):
+    """The shards a rank of north_star's 65 536-trial series owns at N = 8 and N = 4, exactly as bench.py runs them (config 2, product generator,
+    global seeds and jitter, all 299 steps): the library's choice (four lanes per filter with the two-lane arithmetic) against two lanes forced --
+    every logged value of every trial bit for bit, for the three estimators that have the small-batch kernels.  This is what keeps an N-GPU sweep
+    bit-identical to the 1-GPU sweep although its shards run on another kernel."""
+    import ctypes as C
+    import torch
+    import bench
+    K = 299
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = 65536
+    plan = uvs.batch.plan_trials(cfg, cells=[1.5])
+    lo = 65536 - T                                                            # the LAST rank's shard: global trial numbers matter
+    noise = uvs.batch.device_noise(cfg, plan, lo, 65536, K, 'cuda')
+    q0 = torch.as_tensor(plan.q_start[lo:].copy(), device='cuda')
+    des = cfg['experiments']['desired_f']
+    plant = uvs.SyntheticPlant.ur10(des).to_struct()
+    for method in ('GMCKF', 'KF', 'IMCCKF'):
+        outs = []
+        for lanes in (2, 0):
+            fp = uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, des, True, lanes)
+            assert int(uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T)) == (2 if lanes else 4)
+            outs.append(uvs.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err')))
+        two, four = outs
+        assert torch.equal(two['status'], four['status']) and torch.equal(two['k_done'], four['k_done']) and int(two['status'].sum()) == 0
+        for key in ('x', 'err', 'stats'):
+            assert torch.equal(two[key].view(torch.int64), four[key].view(torch.int64)), (method, key)
+        del outs, two, four
+        torch.cuda.empty_cache()
