@@ -964,3 +964,46 @@ def test_small_batch_kernels_at_the_shard_sizes_of_the_strong_series(uvs, T):
             assert torch.equal(two[key].view(torch.int64), four[key].view(torch.int64)), (method, key)
         del outs, two, four
         torch.cuda.empty_cache()
+
+
+def test_segmented_rmckf_launch_is_bit_identical_to_whole_trials(uvs):
+    """RMCKF launches that are not a whole number of rounds of wavefronts run their trials as four work items (the SEGMENTED instantiation of
+    the two-lane kernel, uvs_rmckf_closed_loop_ws_f64): same arithmetic, state through the workspace -- every output equals the whole-trial
+    launch bit for bit.  Forced on a small ragged batch (two lanes fixed: small batches would otherwise take the four-lane kernels) for 2 / 4 /
+    7 segments, and once at a size the library cuts by itself (40 000 trials = 1.22 rounds)."""
+    import ctypes as C
+    import torch
+    g = load_golden('closed_gmckf_a1p5')
+    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    K, T = 120, 150
+    rng = np.random.default_rng(9)
+    q0 = np.tile(g['q_start'], (T, 1)); q0[:, :3] += rng.uniform(-0.2, 0.1, (T, 3))
+    noise = rng.standard_t(1.5, size=(K, 8, T)) * rng.choice([0.3, 1.0, 4.0], size=T)
+    noise[50, 2, 33] = np.nan                                                 # a trial that FAILs inside a segment
+    outs = {}
+    for n in (1, 2, 4, 7):
+        fp = uvs.engine.make_params(8, 6, 'GMCKF', 10.0, True, 0.05, 15.0, 0.2, g['desired'], True, 2, K)
+        fp.reserved = n << 8
+        assert int(uvs.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), T)) == n
+        outs[n] = uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise), want=('x', 'err', 'q', 'f', 'dq'), final_state=True)
+    whole = outs[1]
+    assert int(whole['status'][33]) == 1 and int(whole['k_done'][33]) == 50
+    live = torch.arange(K, device='cuda')[:, None, None] < whole['k_done'][None, None, :]
+    ok = whole['status'] == 0
+    for n in (2, 4, 7):
+        cut = outs[n]
+        assert torch.equal(whole['status'], cut['status']) and torch.equal(whole['k_done'], cut['k_done'])
+        for key in ('x', 'err', 'q', 'f', 'dq'):
+            assert torch.equal(torch.where(live, whole[key], 0.0).view(torch.int64), torch.where(live, cut[key], 0.0).view(torch.int64)), (n, key)
+        for key in ('stats', 'x_final', 'p_final'):
+            assert torch.equal(whole[key][ok].view(torch.int64), cut[key][ok].view(torch.int64)), (n, key)
+    # the library's own choice at 1.22 rounds
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = 40000
+    res = uvs.batch.run_batch(cfg, cells=[1.5], want=('err',))
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
+    assert int(uvs.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), 40000)) == 4
+    fp.reserved = 1 << 8
+    whole = uvs.engine.closed_loop(fp, plant, torch.as_tensor(res.plan.q_start.copy(), device='cuda'), res.noise, want=('err',))
+    assert torch.equal(whole['err'].view(torch.int64), res.streams['err'].view(torch.int64)) and torch.equal(whole['stats'].view(torch.int64), res.stats.view(torch.int64))

@@ -57,13 +57,19 @@ def test_workspace_query_is_host_logic(uvs):
     plant = uvs.SyntheticPlant.ur10().to_struct()
     q = lambda fp, T: int(lib.uvs_rmckf_closed_loop_workspace_bytes(ctypes.byref(fp), ctypes.byref(plant), T))   # noqa: E731
     per_chunk = (3 * 6 + 6 + 4 + 1 + 4 * 21 + 4 * 6 + 12 + 1) * 64 * 8
+    seg = lambda fp, T: int(lib.uvs_rmckf_closed_loop_segments(ctypes.byref(fp), ctypes.byref(plant), T))      # noqa: E731
     mckf = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8))
     assert q(mckf, 32768) == 0                                             # one round of wavefronts: nothing to balance
-    seg = lambda fp, T: int(lib.uvs_rmckf_closed_loop_segments(ctypes.byref(fp), ctypes.byref(plant), T))      # noqa: E731
     assert [seg(mckf, T) for T in (32768, 32769, 65536, 98304, 98305, 1048576)] == [1, 8, 8, 8, 4, 4]
     assert q(mckf, 65536) == 2048 * 4 + 2048 * per_chunk                   # flags + state
     assert q(mckf, 65537) == (2049 * 4 + 255) // 256 * 256 + 2049 * per_chunk
     assert q(uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8)), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 65536) == 0
+    # RMCKF: wavefronts of equal length, so only launches that are not a whole number of rounds (1 024 wavefronts of 32 trials) are cut -- in four
+    rm = uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8))
+    assert [seg(rm, T) for T in (16384, 32768, 36000, 40000, 49152, 65536, 65536 + 2048, 81920, 98304, 131072 + 16384, 196608 + 16384, 16385)] == [1, 1, 1, 4, 4, 1, 1, 4, 1, 4, 1, 1]
+    assert q(rm, 49152) == 1536 * 4 + 1536 * per_chunk and seg(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 49152) == 1
+    rm.reserved = 1                                                        # strict pinv: everything goes to the careful kernels, nothing to cut
+    assert seg(rm, 49152) == 1
     assert q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=4), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=-2), 65536) == 0
     forced = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8)); forced.reserved = 3 << 8
     assert q(forced, 40) == 256 + 2 * per_chunk
@@ -296,7 +302,7 @@ def test_default_kernels_have_no_scratch():
     for method in (2, 3, 4, 5):                                              # KF, MCKF, IMCCKF, GMCKF
         for plant in (0, 1, 2):                                              # DH, linear, DH with the UR10-like table's compile-time zeros
             for xout in ('true', 'false'):
-                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false>']
+                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false, {"true" if method == 3 else "false"}>']
                 assert r['scratch'] == 0 and r['vgpr'] <= 512, (method, plant, xout, r)
                 # KF / IMCC-KF keep one covariance block per lane and must fit two wavefronts per SIMD (256 registers, 8 x 19 KB of LDS per CU)
                 if method in (2, 4):
@@ -306,9 +312,12 @@ def test_default_kernels_have_no_scratch():
     for method in (2, 4, 5):
         for plant in (0, 2):
             for xout in ('true', 'false'):
-                assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, {plant}, 2, {xout}, true>']['scratch'] == 0
+                assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, {plant}, 2, {xout}, true, false>']['scratch'] == 0
         for xout in ('true', 'false'):
-            assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, 0, 2, {xout}, false>']['scratch'] == 0
+            assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, 0, 2, {xout}, false, false>']['scratch'] == 0
+    for plant in (0, 2):                                                     # RMCKF's segmented instantiation (launches that are not a whole number of rounds)
+        for xout in ('true', 'false'):
+            assert k[f'closed_loop_tuned_kernel<8, 6, 2, 5, {plant}, 2, {xout}, false, true>']['scratch'] == 0
     for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true>',
                  'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
         assert k[name]['scratch'] == 0, (name, k[name])

@@ -6,7 +6,7 @@ import collections
 import re
 import sys
 
-KERNEL = '_ZN3uvs24closed_loop_tuned_kernelILi8ELi6ELi2ELi5ELi2ELi2ELb1ELb0EEEvNS_10ClosedArgsE'
+KERNEL = '_ZN3uvs24closed_loop_tuned_kernelILi8ELi6ELi2ELi5ELi2ELi2ELb1ELb0ELb0EEEvNS_10ClosedArgsE'
 # order of the stamps inside one trip of the loop (slot written at the END of the phase): loop top (5), plant (0), vmcnt probe (6), rows (1), control law (2), logs (3)
 PHASES = ['loop edge: sincos advance, integrate q (stamp 5)', 'noise-load issue + plant (0)', 'vmcnt(0) probe (6)', 'row updates (1)', 'control law: QR + solve (2)',
           'logs + statistics (3)']

@@ -675,15 +675,19 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 #ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 #define UVS_SHARED_OCC 2
 #endif
-template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false>
+// SEGMENTED: the instantiation can run a trial chunk as several work items (see SEG below).  Always for MCKF, whose wavefronts differ in length;
+// for RMCKF a second instantiation that the launcher picks only when a launch is not a whole number of rounds of wavefronts (the code costs the
+// headline kernel 4 registers and 0.4 %, so the headline launch keeps the instantiation without it).
+template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF)>
 __global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
     // MCKF trials differ in length (a trial that iterates costs its whole wavefront the fixed-point branch): with exactly two rounds of
     // wavefronts a slow one serialises with its slot's second wavefront.  The two-lane MCKF kernel can therefore run a chunk's K steps as
-    // A.n_seg work items, the state crossing through HBM (uvs_rmckf_closed_loop_ws_f64); same arithmetic, bit-identical results.
-    constexpr bool SEG = (METHOD == UVS_METHOD_MCKF && L == 2 && !XREG && PLANT != UVS_PLANT_LINEAR);   // (the linear-plant instantiation has no registers to spare for it)
+    // A.n_seg work items, the state crossing through HBM (uvs_rmckf_closed_loop_ws_f64); same arithmetic, bit-identical results.  The RMCKF
+    // kernel has a SEGMENTED instantiation for launches that are not a whole number of rounds (1.5 rounds take two rounds' time otherwise).
+    constexpr bool SEG = (SEGMENTED && L == 2 && !XREG && PLANT != UVS_PLANT_LINEAR);   // (the linear-plant instantiations have no registers to spare for it)
     // Split kinematics: the L lanes of a filter form G groups, group g multiplies links g*JG .. g*JG+JG-1 of the DH chain and
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool DH = (PLANT == UVS_PLANT_DH_PINHOLE || PLANT == kPlantDhAxisAligned);

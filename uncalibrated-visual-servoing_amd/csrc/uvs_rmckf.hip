@@ -97,7 +97,10 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap) {
 namespace {
 constexpr int64_t kSimdSlots = 1024;
 int segments_for(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
-    if (!fp || !plant || T <= 0 || fp->method != UVS_METHOD_MCKF || fp->lanes_per_filter < 0 || plant->kind != UVS_PLANT_DH_PINHOLE) return 1;
+    if (!fp || !plant || T <= 0 || fp->lanes_per_filter < 0 || plant->kind != UVS_PLANT_DH_PINHOLE) return 1;
+    const bool mckf = fp->method == UVS_METHOD_MCKF, rmckf = fp->method == UVS_METHOD_GMCKF && fp->m == 8 && fp->n == 6;
+    if (!mckf && !rmckf) return 1;
+    if (fp->reserved & UVS_OPT_STRICT_PINV) return 1;                // (every trial goes to the careful kernels: nothing to cut)
     const int L = fp->lanes_per_filter ? fp->lanes_per_filter : default_lanes(fp->m, fp->n, fp->method);
     bool tuned2 = false;
 #define X(M, N, LL) if (fp->m == M && fp->n == N && L == LL && LL == 2) tuned2 = true;
@@ -106,13 +109,21 @@ int segments_for(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T)
     if (!tuned2) return 1;
     const int forced = (fp->reserved >> 8) & 0xff;
     int n = forced;
-    if (!n) {
-        const int64_t chunks = (T * L + 63) / 64;
+    const int64_t chunks = (T * L + 63) / 64;
+    if (!n && mckf) {
         // measured on MI355X (32 trials per wavefront, one wavefront per SIMD): one round or less -- nothing to balance;
         // up to three rounds -- 8 segments (49 152 trials 4.02 -> 3.15 ms, 65 536: 4.43 -> 4.04, 98 304: 6.46 -> 5.94); beyond -- 4
         // (131 072: 8.24 -> 7.66, 262 144: 15.6 -> 15.0), where 8 hand-overs per chunk cost more than the shorter tail returns
         n = chunks <= kSimdSlots ? 1 : (chunks <= 3 * kSimdSlots ? 8 : 4);
     }
+    if (!n && rmckf) {
+        // RMCKF wavefronts all take the same time, so only a launch that is NOT a whole number of rounds has something to balance: 1.5 rounds take
+        // two rounds' time as whole trials (49 152 trials 2.97 -> 2.65 ms, 81 920: 4.49 -> 4.11 in four segments); whole rounds (the BASELINE configs)
+        // and launches beyond six rounds keep whole trials and the instantiation without the hand-over code
+        const int64_t over = chunks % kSimdSlots;
+        n = (chunks > kSimdSlots && chunks < 6 * kSimdSlots && over >= kSimdSlots / 10 && over <= kSimdSlots - kSimdSlots / 10) ? 4 : 1;
+    }
+    if (small_batch_lanes(fp, plant, T)) n = 1;                      // (small batches run on four lanes per filter: no segmented kernel there, none needed)
     if (n > 16) n = 16;
     if (n > 1 && fp->steps < 8 * n) n = 1;                        // nothing to cut in a short trial
     return n < 1 ? 1 : n;
