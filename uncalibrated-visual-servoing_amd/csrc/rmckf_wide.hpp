@@ -38,6 +38,74 @@ UVS_DEV double pick_lane_value(const double (&v)[N], int idx) {
     return r;
 }
 
+// ---- sums over the 8 lanes of a filter in the BLOCKED lane mapping (L == 8: lane = 8 sub + trial, so the lanes of a filter sit 8 / 16 / 32 apart).
+// The control law needs 36 sums per step on every lane of the filter.  As 36 butterfly all-reduces (the interleaved mapping: three DPP stages of
+// 2 moves + 1 add each) that is 324 instructions; here it is a reduce-scatter / all-gather: v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another, so ONE pair of swaps + one add folds lane bit 5 of TWO values at once (each half of the wavefront keeps
+// one of them), v_permlane16_swap does the same for lane bit 4 between the 16-lane rows, the last stage (lane bit 3) is a plain DPP row rotate by 8
+// on the quarter of the values that is left; two gather stages (copy + swap) hand the totals back.  18 x 3 + 9 x 3 + 9 x 3 + 9 x 4 + 18 x 4 = 216.
+// Every lane of a filter receives the same bits (each total is computed once, then copied).
+UVS_DEV void swap_halves(double &a, double &b) {                   // a = [a.lo | b.lo], b = [a.hi | b.hi]   (halves of 32 lanes)
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+UVS_DEV void swap_rows(double &a, double &b) {                     // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]   (rows of 16 lanes)
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+constexpr int kDppRowRor8 = 0x128;
+template <int NV>
+UVS_DEV void blocked_sums8(double (&v)[NV]) {
+    constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2;
+    double u[N1], w[N2];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {                                 // lane bit 5: lower half keeps v[2 i], upper half v[2 i + 1]
+        double a = v[2 * i], b = v[2 * i + 1 < NV ? 2 * i + 1 : 2 * i];
+        swap_halves(a, b);
+        u[i] = a + b;
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {                                 // lane bit 4: even rows keep u[2 i], odd rows u[2 i + 1]
+        double a = u[2 * i], b = u[2 * i + 1 < N1 ? 2 * i + 1 : 2 * i];
+        swap_rows(a, b);
+        w[i] = a + b;
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) w[i] += dpp_mov64<kDppRowRor8>(w[i]);   // lane bit 3
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        double a = w[i], b = w[i];
+        swap_rows(a, b);
+        u[2 * i] = a;
+        if (2 * i + 1 < N1) u[2 * i + 1] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+        double a = u[i], b = u[i];
+        swap_halves(a, b);
+        v[2 * i] = a;
+        if (2 * i + 1 < NV) v[2 * i + 1] = b;
+    }
+}
+UVS_DEV double blocked_sum8(double v) {                            // one value: all-reduce over lane bits 5, 4, 3
+    double a = v, b = v;
+    swap_halves(a, b);
+    v = a + b;
+    a = v; b = v;
+    swap_rows(a, b);
+    v = a + b;
+    return v + dpp_mov64<kDppRowRor8>(v);
+}
+template <int L>
+UVS_DEV double wide_sum(double v) {
+    if constexpr (L == 8) return blocked_sum8(v);
+    else return group_sum<L>(v);
+}
+
 // XREC: the X stream is laid out as per-trial records ([step][trial][component]: comp_stride 1, trial_stride M N).  The TPW trials of a
 // wavefront then own one contiguous block of TPW M N doubles per step (14 KB at (32,7), L = 8): the rows go through LDS once and leave as
 // 16-byte-per-lane stores of 1 KB each, fully coalesced.  In the trial-fastest layout of the (8,6) kernels a wavefront of 8 trials can only
@@ -61,9 +129,10 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     __shared__ double lp[PL > 0 ? PL * NP : 1][64];
 
     const unsigned lane = threadIdx.x;
-    const int sub = (int)(lane & (L - 1));
+    // L == 8: blocked mapping, lane = TPW sub + trial (the sums above); L == 16: the lanes of a filter are one DPP row
+    const int sub = (L == 8) ? (int)(lane / TPW) : (int)(lane & (L - 1));
     const long long wave_first = (long long)blockIdx.x * TPW;
-    const unsigned tl = lane / L;
+    const unsigned tl = (L == 8) ? lane % TPW : lane / L;
     const bool valid = wave_first + tl < A.T;
     const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial (duplicate values, same addresses)
     const uvs_filter_params &fp = A.fp;
@@ -164,7 +233,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 const double nu = zi[r] - pred;
                 ss = fma(nu, nu, ss);
             }
-            c_shared = exp_nonpos(group_sum<L>(ss) * neg_half_inv_s2);
+            c_shared = exp_nonpos(wide_sum<L>(ss) * neg_half_inv_s2);
         }
         // ---- estimator rows (experiment.py:166-297)
         double chk = 0.0;
@@ -222,14 +291,6 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         }
         (void)pxr;
         if (px) px += A.x_out.sk;
-        chk = group_sum<L>(chk);
-        if (alive && !(chk == 0.0)) {                              // X turned non-finite: pinv would raise (experiment.py:313-316)
-            alive = false;
-            status = UVS_STATUS_FAIL;
-            k_done = k;
-        }
-        if (!__any(alive)) break;
-
         // ---- control law dq = -gain pinv(X)(kappa o err) (experiment.py:300-312): normal equations + one refinement step
         double G[NP], b[N], y[R];
 #pragma unroll
@@ -247,10 +308,32 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 b[l] = fma(x[r][l], y[r], b[l]);
             }
         }
+        if constexpr (L == 8) {                                    // one batch: Gram matrix, right-hand side and the finiteness probe
+            double v[NP + N + 1];
 #pragma unroll
-        for (int e = 0; e < NP; ++e) G[e] = group_sum<L>(G[e]);    // independent sums: they pipeline
+            for (int e = 0; e < NP; ++e) v[e] = G[e];
 #pragma unroll
-        for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
+            for (int j = 0; j < N; ++j) v[NP + j] = b[j];
+            v[NP + N] = chk;
+            blocked_sums8(v);
+#pragma unroll
+            for (int e = 0; e < NP; ++e) G[e] = v[e];
+#pragma unroll
+            for (int j = 0; j < N; ++j) b[j] = v[NP + j];
+            chk = v[NP + N];
+        } else {
+            chk = group_sum<L>(chk);
+#pragma unroll
+            for (int e = 0; e < NP; ++e) G[e] = group_sum<L>(G[e]);    // independent sums: they pipeline
+#pragma unroll
+            for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
+        }
+        if (alive && !(chk == 0.0)) {                              // X turned non-finite: pinv would raise (experiment.py:313-316)
+            alive = false;
+            status = UVS_STATUS_FAIL;
+            k_done = k;
+        }
+        if (!__any(alive)) break;
         UVS_WIDE_FENCE();
         double rs[N];
         const bool suspect = chol_factor<N, false>(G, rs);       // (pivot spread only: no register left for the column-norm watch, see chol_factor)
@@ -267,8 +350,11 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
             for (int j = 0; j < N; ++j) c[j] = fma(x[r][j], ri, c[j]);
         }
+        if constexpr (L == 8) blocked_sums8(c);
+        else {
 #pragma unroll
-        for (int j = 0; j < N; ++j) c[j] = group_sum<L>(c[j]);
+            for (int j = 0; j < N; ++j) c[j] = group_sum<L>(c[j]);
+        }
         chol_solve_inplace<N>(G, rs, c);
 #pragma unroll
         for (int j = 0; j < N; ++j) dq[j] = -fp.gain * (b[j] + c[j]);
@@ -307,7 +393,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         double v = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) v = fma(lacc[c * R + r][lane], lacc[c * R + r][lane], v);
-        s2[c] = group_sum<L>(v);
+        s2[c] = wide_sum<L>(v);
     }
     if (!valid) return;
     if (sub == 0) {
