@@ -1,15 +1,16 @@
 // Tuned closed-loop kernel for the wide stress shape (BASELINE config 5: m = 32 rows, n = 7 joints, linear consistent plant).
 //
 // Sizing.  A filter is 32 covariance blocks of 28 doubles + 224 doubles of X = 8.96 KB (the reference's dense 224 x 224 P would be
-// 401 KB and cannot exist on chip at all).  L = 8 adjacent lanes share a filter, lane `sub` owning rows sub, sub + 8, sub + 16, sub + 24:
+// 401 KB and cannot exist on chip at all).  L = 8 lanes share a filter (lanes 8 apart: lane = 8 sub + trial), lane `sub` owning rows sub, sub + 8, sub + 16, sub + 24:
 // 140 doubles of state per lane, so one wavefront per SIMD (512 registers; what does not fit the 256 VALU-addressable ones the compiler
 // parks in AGPRs), 8 trials per wavefront.
 //
 // What differs from the generic template that served this shape before (45-52 ms per 65 536 x 299 sweep):
 //   * control law by the normal equations with one refinement step instead of Householder QR across 16 lanes.  Each lane accumulates
-//     J^T J and J^T y over its own rows, ONE batch of 35 independent group sums follows (the QR needs 35 sums too, but one after the
-//     other, each on the critical path, plus a replicated sqrt / reciprocal chain per column), then every lane factors the 7 x 7
-//     Gram matrix itself; the refinement step costs 7 more sums.  Accuracy: rmckf_device.hpp, "normal equations";
+//     J^T J and J^T y over its own rows, ONE batch of 36 independent group sums follows (the QR needs 35 sums too, but one after the
+//     other, each on the critical path, plus a replicated sqrt / reciprocal chain per column) -- at L = 8 as a reduce-scatter /
+//     all-gather over v_permlane32_swap / v_permlane16_swap (blocked_sums8 below) --, then every lane factors the 7 x 7 Gram matrix
+//     itself; the refinement step costs 7 more sums.  Accuracy: rmckf_device.hpp, "normal equations";
 //   * estimator selected at compile time, rows through the same rmckf_row as the (8,6) kernels;
 //   * plant matrix rows and desired features in LDS, joints replicated on the 8 lanes (no exchange), stream cursors instead of
 //     per-element address arithmetic, next step's noise fetched one step ahead.
