@@ -72,5 +72,8 @@ void debug_math(int which, long long n, const double *x, double *y, hipStream_t 
 void noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s);
 int noise_variant(const uvs_noise_params &np);                       // 0 = kernel of np.type, 1 = beta = 0 alpha-stable specialisation
 void pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s);
+// p[0..n) = v as a KERNEL: inside a captured graph a memset node in front of the closed-loop kernel was seen to land late on every other replay
+// (ROCm 7.2, tests/test_gpu_graph.py), a kernel node keeps its place in the stream's order
+void fill_i32(int *p, int v, long long n, hipStream_t s);
 
 }  // namespace uvs_launch

@@ -12,6 +12,15 @@ bool uvs_launch::step_generic(int m, int n, int L, int64_t T, hipStream_t s, con
     return false;
 }
 
+namespace uvs {
+__global__ void fill_i32_kernel(int *p, int v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace uvs
+void uvs_launch::fill_i32(int *p, int v, long long n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(uvs::fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+}
 void uvs_launch::stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *out, hipStream_t s) {
     hipLaunchKernelGGL(uvs::stats_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, T, K, m, err, t, k_done, out);
 }

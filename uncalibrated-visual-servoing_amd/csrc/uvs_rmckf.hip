@@ -215,7 +215,7 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
     if (fp->reserved & UVS_OPT_STRICT_PINV) {                      // numpy's pinv on every solve: mark every trial, the careful pass below is the only pass
-        if (hipMemsetD32Async((hipDeviceptr_t)status, uvs::UVS_STATUS_SUSPECT, (size_t)T, s) != hipSuccess) return check_launch("strict pinv: marking the trials");
+        uvs_launch::fill_i32(status, uvs::UVS_STATUS_SUSPECT, (long long)T, s);
         launched = true;
     }
 #ifdef UVS_HAVE_EMU2
@@ -262,7 +262,7 @@ int uvs_rmckf_replay_f64(const uvs_filter_params *fp, int64_t T, uvs_view f, uvs
     if (tuned_method && !dqcmd_out.base && (fp->lanes_per_filter == 0 || fp->lanes_per_filter == 4))
         launched = replay_rows(fp->m, fp->n, fp->method, fp->lanes_per_filter == 0, x_out.base != nullptr, err_out.base != nullptr, T, s, A);
     if ((fp->reserved & UVS_OPT_STRICT_PINV) && dqcmd_out.base) {   // numpy's pinv on every solve: the careful pass below is the only pass
-        if (hipMemsetD32Async((hipDeviceptr_t)status, uvs::UVS_STATUS_SUSPECT, (size_t)T, s) != hipSuccess) return check_launch("strict pinv: marking the trials");
+        uvs_launch::fill_i32(status, uvs::UVS_STATUS_SUSPECT, (long long)T, s);
         launched = true;
     }
     // with the commanded dq (library default lanes, KF / RMCKF, X and err wanted too): the same estimator wavefronts + control wavefronts
