@@ -15,6 +15,7 @@ ap.add_argument('--lanes', default='2,4')
 ap.add_argument('--trials', default='8192,16384,32768,65536')
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--method', default='GMCKF')
+ap.add_argument('--latency', action='store_true', help='UVS_OPT_LATENCY (with --lanes 0)')
 args = ap.parse_args()
 dev = torch.device('cuda')
 K = len(engine.loop_clock(0.05, 15))
@@ -27,6 +28,8 @@ for T in [int(t) for t in args.trials.split(',')]:
     plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
     for L in [int(x) for x in args.lanes.split(',')]:
         fp = engine.make_params(8, 6, args.method, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, L)
+        if args.latency:
+            fp.reserved = 2
         ms = []
         for i in range(3 + args.reps):
             out = engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))

@@ -111,14 +111,24 @@ UVS_DEV double wide_sum(double v) {
 // wavefront then own one contiguous block of TPW M N doubles per step (14 KB at (32,7), L = 8): the rows go through LDS once and leave as
 // 16-byte-per-lane stores of 1 KB each, fully coalesced.  In the trial-fastest layout of the (8,6) kernels a wavefront of 8 trials can only
 // write 64-byte pieces (8 trials x 8 B per component row), which is what held the generic template at 50 ms.
-template <int M, int N, int L, int METHOD, bool XOUT, bool XREC>
+//
+// PLANT = UVS_PLANT_DH_PINHOLE (round 4): the same kernel as an EIGHT-lane mapping of the (8,6) shape -- one row (one image coordinate) per lane, 8
+// trials per wavefront, so that a shard of 8 192 trials (a rank's share of north_star's 65 536-trial series on 8 GPUs) is one round of 1 024
+// wavefronts.  The kinematic chain is replicated on the 8 lanes of a filter (no exchange): joint sines / cosines carried from step to step by
+// the addition theorems as in the tuned kernels, the chain applied right to left to the three columns a lane needs (its camera axis, the
+// optical axis, the position).  Built as the latency mapping VERDICT r3 asked to be measured; measured: 8 192 trials 0.92 ms against 0.88 ms on
+// four lanes per filter -- a lone wavefront's step is its dependent chain (sincos -> chain -> row -> factorisation -> two substitutions), not
+// its instruction count.  Reachable with lanes_per_filter = 8 (instead of the generic template); no launch policy selects it.
+template <int M, int N, int L, int METHOD, bool XOUT, bool XREC, int PLANT = UVS_PLANT_LINEAR>
 __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loop_wide_kernel(const ClosedArgs A) {
     static_assert(M % L == 0 && M >= N && (L == 8 || L == 16), "wide kernel: rows interleaved over 8 or 16 adjacent lanes (one DPP row)");
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;
+    constexpr bool DH = PLANT != UVS_PLANT_LINEAR;
+    static_assert(!DH || (R == 1 && !XREC), "DH plant: one row per lane (initial_guess numbers a lane's rows sub R + r), streams in the caller's strides");
     constexpr int REC = M * N, RECP = REC + 1;                     // record length, padded in LDS against bank conflicts
     static_assert(!XREC || (TPW * REC) % 128 == 0, "record path: a whole number of 1 KB stores per wavefront");
-    __shared__ double lJ[M][N];                                    // plant matrix
-    __shared__ double lc[M], ldes[M];                              // f0 - J q0, desired_f
+    __shared__ double lJ[DH ? 1 : M][N];                           // plant matrix (linear plant)
+    __shared__ double lc[DH ? 1 : M], ldes[M];                     // f0 - J q0, desired_f
     __shared__ double lt[XREC ? TPW * RECP : 1];                   // transposition buffer of the X records
     __shared__ double lacc[3 * R][64], lfp[R][64];                 // lane-private: ISE / IAE / ITAE accumulators, previous noisy features
     // KF and IMCC-KF weigh every row of a filter alike, so all their covariance blocks stay identical (RowShare, rmckf_tuned.hpp): a lane keeps
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     // through registers while their row is updated: with all four in registers (L = 8) the compiler overflows VGPRs + AGPRs and spills
     // ~60 dwords per lane to scratch.
     constexpr bool SHARED_P = (METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF);
-    constexpr int PV = SHARED_P ? 1 : ((L == 8) ? R - 1 : R), PL = SHARED_P ? 0 : R - PV;
+    constexpr int PV = SHARED_P ? 1 : ((L == 8 && R > 1) ? R - 1 : R), PL = SHARED_P ? 0 : R - PV;
     __shared__ double lp[PL > 0 ? PL * NP : 1][64];
 
     const unsigned lane = threadIdx.x;
@@ -140,13 +150,15 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     const int K = fp.steps;
 
     for (int i = (int)lane; i < M; i += 64) {
-        double c = A.plant.lin_f0[i];
-        for (int j = 0; j < N; ++j) {
-            const double v = A.plant.lin_jacobian[i * N + j];
-            lJ[i][j] = v;
-            c = fma(-v, A.plant.lin_q0[j], c);
+        if constexpr (!DH) {
+            double c = A.plant.lin_f0[i];
+            for (int j = 0; j < N; ++j) {
+                const double v = A.plant.lin_jacobian[i * N + j];
+                lJ[i][j] = v;
+                c = fma(-v, A.plant.lin_q0[j], c);
+            }
+            lc[i] = c;
         }
-        lc[i] = c;
         ldes[i] = fp.desired[i];
     }
     __syncthreads();
@@ -163,12 +175,22 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     double q[N], dq[N], x[R][N], p[PV][NP];
 #pragma unroll
     for (int j = 0; j < N; ++j) { q[j] = *A.q_start.at(trial, 0, j); dq[j] = 0.0; }     // first_run: H = 0 (experiment.py:183-185)
+    double f_first[R];
+    bool guessed = false;
+    if constexpr (DH) {
+        if (fp.initial_guess) {                                    // X0 = analytic Jacobian at q_start, f = the noise-free features there (experiment.py:86-114)
+            initial_guess<M, N, L>(A.plant, q, sub, x, f_first);
+            guessed = true;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = r * L + sub;
-        lfp[r][lane] = 0.0;                                        // f = zeros(m) (experiment.py:56): no analytic initial guess on this plant
+        lfp[r][lane] = guessed ? f_first[r] : 0.0;                 // else f = zeros(m) (experiment.py:56)
+        if (!guessed) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) x[r][j] = *A.x0.at(trial, 0, row * N + j);
+            for (int j = 0; j < N; ++j) x[r][j] = *A.x0.at(trial, 0, row * N + j);
+        }
 #pragma unroll
         for (int l = 0; l < N; ++l)
 #pragma unroll
@@ -198,6 +220,18 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
     double t = fp.dt;
     int status = UVS_STATUS_SUCCESS, k_done = K;
     bool alive = true, flagged = false;
+    // DH plant: the lane's image coordinate (row = sub: point sub / 2, u for even rows, v for odd ones) and the tracked sines / cosines
+    double sn[DH ? N : 1], cs[DH ? N : 1], wpt[3] = {0.0, 0.0, 0.0};
+    bool reseed = true;
+    const bool odd = (sub & 1) != 0;
+    if constexpr (DH) {
+#pragma unroll
+        for (int pt = 0; pt < M / 2; ++pt)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wpt[c] = ((sub >> 1) == pt) ? A.plant.points[pt][c] : wpt[c];
+#pragma unroll
+        for (int u = 0; u < N; ++u) { sn[u] = 0.0; cs[u] = 1.0; }
+    }
 
     for (int k = 0; k < K; ++k) {
         double nz[R];
@@ -210,12 +244,69 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         }
         // ---- plant + measurement (experiment.py:134-135, 170-177, 302)
         double zi[R], err[R], kap[R];
+        double z_dh = 0.0;
+        if constexpr (DH) {
+            // sines / cosines of the joint angles: carried by sincos_advance, re-seeded from the angle every kSinCosResync steps or at once after
+            // a step too large for the polynomials (decided per lane; the lanes of a filter hold the same joints, so they decide alike)
+            const bool need = reseed || (k & (kSinCosResync - 1)) == 0;
+            if (__any(need)) {
+                double th[N], s_new[N], c_new[N];
+                bool big = false;
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    th[u] = q[u] + A.plant.theta_offset[u];
+                    big |= !(fabs(th[u]) <= kSinCosBoundedMax);
+                    sincos_bounded(th[u], s_new[u], c_new[u]);
+                }
+                if (__builtin_expect(__any(need && big), 0)) {
+#pragma unroll
+                    for (int u = 0; u < N; ++u) {
+                        double sl, cl;
+                        sincos(th[u], &sl, &cl);
+                        s_new[u] = big ? sl : s_new[u];
+                        c_new[u] = big ? cl : c_new[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    sn[u] = need ? s_new[u] : sn[u];
+                    cs[u] = need ? c_new[u] : cs[u];
+                }
+                reseed = false;
+            }
+            // link = Rz(theta) Tz(d) Rx(alpha) Tx(a) (ur10_simulation.py:204-211); T = A_0 ... A_{N-1} applied right to left to three columns
+            double va[3], vz[3], vp[3];
+            {
+                const double s = sn[N - 1], c = cs[N - 1], ca = A.plant.cos_alpha[N - 1], sa = A.plant.sin_alpha[N - 1], aa = A.plant.a[N - 1];
+                va[0] = odd ? -s * ca : c; va[1] = odd ? c * ca : s; va[2] = odd ? sa : 0.0;
+                vz[0] = s * sa; vz[1] = -c * sa; vz[2] = ca;
+                vp[0] = aa * c; vp[1] = aa * s; vp[2] = A.plant.d[N - 1];
+            }
+#pragma unroll
+            for (int i = N - 2; i >= 0; --i) {
+                const double s = sn[i], c = cs[i], ca = A.plant.cos_alpha[i], sa = A.plant.sin_alpha[i], aa = A.plant.a[i], dd = A.plant.d[i];
+                const double l01 = -s * ca, l02 = s * sa, l03 = aa * c, l11 = c * ca, l12 = -c * sa, l13 = aa * s;
+                const double a0 = fma(c, va[0], fma(l01, va[1], l02 * va[2])), a1 = fma(s, va[0], fma(l11, va[1], l12 * va[2])), a2 = fma(sa, va[1], ca * va[2]);
+                const double z0 = fma(c, vz[0], fma(l01, vz[1], l02 * vz[2])), z1 = fma(s, vz[0], fma(l11, vz[1], l12 * vz[2])), z2 = fma(sa, vz[1], ca * vz[2]);
+                const double p0 = fma(c, vp[0], fma(l01, vp[1], fma(l02, vp[2], l03))), p1 = fma(s, vp[0], fma(l11, vp[1], fma(l12, vp[2], l13))),
+                             p2 = fma(sa, vp[1], fma(ca, vp[2], dd));
+                va[0] = a0; va[1] = a1; va[2] = a2; vz[0] = z0; vz[1] = z1; vz[2] = z2; vp[0] = p0; vp[1] = p1; vp[2] = p2;
+            }
+            const double dx = wpt[0] - vp[0], dy = wpt[1] - vp[1], dz = wpt[2] - vp[2];      // pinhole image coordinate: R^T (w - t), ur10_simulation.py:141-154
+            const double ic = fma(va[0], dx, fma(va[1], dy, va[2] * dz));
+            const double iz = fast_rcp(fma(vz[0], dx, fma(vz[1], dy, vz[2] * dz)));
+            z_dh = fma(A.plant.focal * ic, iz, A.plant.center);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = r * L + sub;
-            double f = lc[row];
+            double f;
+            if constexpr (DH) f = z_dh;
+            else {
+                f = lc[row];
 #pragma unroll
-            for (int j = 0; j < N; ++j) f = fma(lJ[row][j], q[j], f);
+                for (int j = 0; j < N; ++j) f = fma(lJ[row][j], q[j], f);
+            }
             f += nz[r];
             zi[r] = f - lfp[r][lane];
             err[r] = f - ldes[row];
@@ -337,7 +428,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         if (!__any(alive)) break;
         UVS_WIDE_FENCE();
         double rs[N];
-        const bool suspect = chol_factor<N, false>(G, rs);       // (pivot spread only: no register left for the column-norm watch, see chol_factor)
+        const bool suspect = chol_factor<N, DH>(G, rs);          // (wide shape: pivot spread only -- no register left for the column-norm watch, see chol_factor; the (8,6) latency kernel has them)
         flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
         chol_solve_inplace<N>(G, rs, b);                           // s0
         double c[N];
@@ -382,6 +473,14 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             lacc[r][lane] = fma(e, e, lacc[r][lane]);
             lacc[R + r][lane] += ae;
             lacc[2 * R + r][lane] = fma(t, ae, lacc[2 * R + r][lane]);
+        }
+        if constexpr (DH) {
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const double d = dq[u] * fp.dt;
+                reseed |= !(fabs(d) <= kSinCosStepMax);            // too large for the polynomials, or not finite: re-seed at the next step
+                sincos_advance(sn[u], cs[u], d);
+            }
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) q[j] = fma(dq[j], fp.dt, q[j]);            // new_q = q + dq t_s (experiment.py:320)

@@ -69,6 +69,9 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
 // no four-lane tuned kernel and keeps two lanes.  Returns 0 = no change, 4 = plain four lanes, -4 = four lanes with the two-lane bits.
 int small_batch_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
     if (fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF || (T * 4 + 63) / 64 > 1024) return 0;
+    // (eight lanes per filter -- one row per lane on the wide kernel's DH instantiation, lanes_per_filter = 8 -- were built and measured for this
+    // role: 8 192 trials 0.92 ms against 0.88 ms on four lanes.  A lone wavefront's step is bound by its dependent chain, not by its instruction
+    // count, so more lanes do not shorten it: DESIGN.md A.0)
     if (fp->reserved & UVS_OPT_LATENCY) return 4;
 #ifdef UVS_HAVE_EMU2
     if (plant->kind == UVS_PLANT_DH_PINHOLE && !(fp->reserved & UVS_OPT_STRICT_PINV)) return -4;
