@@ -318,7 +318,7 @@ def test_default_kernels_have_no_scratch():
     for plant in (0, 2):                                                     # RMCKF's segmented instantiation (launches that are not a whole number of rounds)
         for xout in ('true', 'false'):
             assert k[f'closed_loop_tuned_kernel<8, 6, 2, 5, {plant}, 2, {xout}, false, true>']['scratch'] == 0
-    for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true>',
+    for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true, 1>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true, 1>', 'closed_loop_wide_kernel<8, 6, 8, 5, true, false, 0>',
                  'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
         assert k[name]['scratch'] == 0, (name, k[name])
 

@@ -58,7 +58,7 @@ doc = {'round': rnd, 'workload': 'BASELINE config 2, 65536 trials x 299 updates,
                'within 0.5 %, which supports applying it here); fp64 FLOP = 64 lanes x (2 FMA + MUL + ADD + TRANS) wave-instructions'}
 doc.update(head)
 doc['config3'] = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true', 524288, U3 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
-doc['config5'] = entry('closed_loop_wide_kernel<32, 7, 8, 5, true, true>', 524288, U2 * 2360, 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>')
+doc['config5'] = entry('closed_loop_wide_kernel<32, 7, 8, 5, true, true', 524288, U2 * 2360, 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>')
 # (MCKF since round 4: 8 work items per trial chunk, grid 2048 x 8 x 64 -- its hand-over traffic, 141 doubles per lane and segment edge out and back, is part of the counters)
 doc['other_estimators'] = {name: entry(f'tuned_kernel<8, 6, 2, {code}, 2, 2, true', 1048576 if name == 'MCKF' else 131072, U2 * 560,
                                        f'closed_loop_tuned_kernel<8,6,2,{name},DH(axis-aligned),2,true>' + (' (8 segments per trial)' if name == 'MCKF' else ''))
