@@ -117,8 +117,8 @@ UVS_DEV double wide_sum(double v) {
 // wavefronts.  The kinematic chain is replicated on the 8 lanes of a filter (no exchange): joint sines / cosines carried from step to step by
 // the addition theorems as in the tuned kernels, the chain applied right to left to the three columns a lane needs (its camera axis, the
 // optical axis, the position).  Built as the latency mapping VERDICT r3 asked to be measured; measured: 8 192 trials 0.92 ms against 0.88 ms on
-// four lanes per filter -- a lone wavefront's step is its dependent chain (sincos -> chain -> row -> factorisation -> two substitutions), not
-// its instruction count.  Reachable with lanes_per_filter = 8 (instead of the generic template); no launch policy selects it.
+// four lanes per filter -- 1 075 VALU instructions per wavefront-step against 1 109 (PMC): the replicated plant (~300) gives back what one row per
+// lane saves.  Reachable with lanes_per_filter = 8 (instead of the generic template); no launch policy selects it.
 template <int M, int N, int L, int METHOD, bool XOUT, bool XREC, int PLANT = UVS_PLANT_LINEAR>
 __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loop_wide_kernel(const ClosedArgs A) {
     static_assert(M % L == 0 && M >= N && (L == 8 || L == 16), "wide kernel: rows interleaved over 8 or 16 adjacent lanes (one DPP row)");

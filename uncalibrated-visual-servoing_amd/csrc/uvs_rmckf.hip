@@ -70,8 +70,8 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
 int small_batch_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
     if (fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF || (T * 4 + 63) / 64 > 1024) return 0;
     // (eight lanes per filter -- one row per lane on the wide kernel's DH instantiation, lanes_per_filter = 8 -- were built and measured for this
-    // role: 8 192 trials 0.92 ms against 0.88 ms on four lanes.  A lone wavefront's step is bound by its dependent chain, not by its instruction
-    // count, so more lanes do not shorten it: DESIGN.md A.0)
+    // role: 8 192 trials 0.92 ms against 0.88 ms on four lanes -- the plant replicated on eight lanes gives back what one row per lane saves
+    // (1 075 against 1 109 VALU instructions per wavefront-step): DESIGN.md section 6)
     if (fp->reserved & UVS_OPT_LATENCY) return 4;
 #ifdef UVS_HAVE_EMU2
     if (plant->kind == UVS_PLANT_DH_PINHOLE && !(fp->reserved & UVS_OPT_STRICT_PINV)) return -4;
