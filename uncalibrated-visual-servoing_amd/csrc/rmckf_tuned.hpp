@@ -682,7 +682,11 @@ template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EM
 __global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
+#ifdef UVS_L4_XLDS
+    constexpr bool XREG = false;
+#else
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
+#endif
     // MCKF trials differ in length (a trial that iterates costs its whole wavefront the fixed-point branch): with exactly two rounds of
     // wavefronts a slow one serialises with its slot's second wavefront.  The two-lane MCKF kernel can therefore run a chunk's K steps as
     // A.n_seg work items, the state crossing through HBM (uvs_rmckf_closed_loop_ws_f64); same arithmetic, bit-identical results.  The RMCKF
