@@ -1,0 +1,34 @@
+"""More closed-loop fixtures for the estimators of SURVEY 8f rank 2 -- KF, IMCC-KF and MCKF under the noise types, the outlier hold and the
+bandwidth annealing the first generator exercises for RMCKF only.
+
+BUILD-CONTAINER ONLY (imports /root/reference through gen_golden.py; only the .npz vectors travel).  Every run is the UNMODIFIED reference's
+``Experiment.run()`` (experiment.py:48-359) on the plant of SURVEY Appendix A, recorded as in gen_golden.py.
+
+    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the ten listed in main)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G                                                # noqa: E402
+
+
+def main():
+    M, NT = G.E.Method, G.NoiseType
+    MIX = dict(std=1.0, mean=50.0, rho=0.1)
+    AS = lambda a: dict(alpha=a, beta=0, gamma=1, delta=0)             # noqa: E731
+    G.save_closed('kf_white', M.KF, NT.WHITE_NOISE, dict(std=1.0), 223456, x_stride=8)
+    G.save_closed('kf_mix', M.KF, NT.GAUSSIAN_MIXTURE, dict(std=1.0, mean=50.0, rho=0.02), 223457, x_stride=8)    # (rho = 0.1 or the hold make the plain KF diverge: a chaotic run pins nothing)
+    G.save_closed('kf_bimodal', M.KF, NT.GAUSSIAN_BIMODAL, MIX, 223458, x_stride=8)
+    G.save_closed('imcckf_white', M.IMCCKF, NT.WHITE_NOISE, dict(std=1.0), 223459, x_stride=8)
+    G.save_closed('imcckf_mix_anneal', M.IMCCKF, NT.GAUSSIAN_MIXTURE, MIX, 223460, annealing=True, x_stride=8)
+    G.save_closed('imcckf_bimodal', M.IMCCKF, NT.GAUSSIAN_BIMODAL, MIX, 223461, x_stride=8)
+    G.save_closed('imcckf_a1p5_hold', M.IMCCKF, NT.ALPHA_STABLE, AS(1.5), 223465, hold=True, x_stride=8)
+    G.save_closed('mckf_white', M.MCKF, NT.WHITE_NOISE, dict(std=1.0), 223462, x_stride=8)
+    G.save_closed('mckf_mix_anneal', M.MCKF, NT.GAUSSIAN_MIXTURE, MIX, 223463, annealing=True, x_stride=8)
+    G.save_closed('mckf_a1p5_hold', M.MCKF, NT.ALPHA_STABLE, AS(1.5), 223464, hold=True, x_stride=8)
+
+
+if __name__ == '__main__':
+    main()
