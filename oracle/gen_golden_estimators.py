@@ -4,7 +4,7 @@ bandwidth annealing the first generator exercises for RMCKF only.
 BUILD-CONTAINER ONLY (imports /root/reference through gen_golden.py; only the .npz vectors travel).  Every run is the UNMODIFIED reference's
 ``Experiment.run()`` (experiment.py:48-359) on the plant of SURVEY Appendix A, recorded as in gen_golden.py.
 
-    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the ten listed in main)
+    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the fourteen listed in main)
 """
 import os
 import sys
@@ -28,6 +28,15 @@ def main():
     G.save_closed('mckf_white', M.MCKF, NT.WHITE_NOISE, dict(std=1.0), 223462, x_stride=8)
     G.save_closed('mckf_mix_anneal', M.MCKF, NT.GAUSSIAN_MIXTURE, MIX, 223463, annealing=True, x_stride=8)
     G.save_closed('mckf_a1p5_hold', M.MCKF, NT.ALPHA_STABLE, AS(1.5), 223464, hold=True, x_stride=8)
+    # other clocks and gains than config.json's 0.05 s / 15 s / 0.2: the loop count of experiment.py:150-152 (t accumulated in floating point),
+    # the annealing span (experiment.py:267-271) and the control gain
+    for name, meth, dt, t_max, gain, kw in (('gmckf_dt0p02_t6_gain0p5_anneal', M.GMCKF, 0.02, 6, 0.5, dict(annealing=True)),
+                                            ('gmckf_dt0p1_t20_gain0p1', M.GMCKF, 0.1, 20, 0.1, {}),
+                                            ('mckf_dt0p02_t4_gain0p4', M.MCKF, 0.02, 4, 0.4, {}),
+                                            ('kf_dt0p03_t7_gain0p3', M.KF, 0.03, 7, 0.3, {})):
+        G.DT, G.T_MAX, G.GAIN = dt, t_max, gain
+        G.save_closed(name, meth, NT.ALPHA_STABLE, AS(1.5), 323456, x_stride=8, **kw)
+    G.DT, G.T_MAX, G.GAIN = 0.05, 15, 0.2
 
 
 if __name__ == '__main__':
