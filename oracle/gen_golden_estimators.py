@@ -4,7 +4,7 @@ bandwidth annealing the first generator exercises for RMCKF only.
 BUILD-CONTAINER ONLY (imports /root/reference through gen_golden.py; only the .npz vectors travel).  Every run is the UNMODIFIED reference's
 ``Experiment.run()`` (experiment.py:48-359) on the plant of SURVEY Appendix A, recorded as in gen_golden.py.
 
-    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the fourteen listed in main)
+    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the sixteen listed in main)
 """
 import os
 import sys
@@ -37,6 +37,9 @@ def main():
         G.DT, G.T_MAX, G.GAIN = dt, t_max, gain
         G.save_closed(name, meth, NT.ALPHA_STABLE, AS(1.5), 323456, x_stride=8, **kw)
     G.DT, G.T_MAX, G.GAIN = 0.05, 15, 0.2
+    # other kernel bandwidths for the estimators with ONE weight per filter / per state entry
+    G.save_closed('imcckf_sigma30_anneal', M.IMCCKF, NT.ALPHA_STABLE, AS(1.5), 423457, kernel_bw=30, annealing=True, x_stride=8)
+    G.save_closed('mckf_sigma30', M.MCKF, NT.ALPHA_STABLE, AS(1.2), 423458, kernel_bw=30, x_stride=8)
 
 
 if __name__ == '__main__':
