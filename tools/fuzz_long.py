@@ -26,7 +26,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
     cfg = bench.config2()
     desired = cfg['experiments']['desired_f']
-    lanes_of = {'GMCKF': [0, 2, 4, 1, -2], 'KF': [0, 2, 4, -4], 'IMCCKF': [0, 2, 4, -2], 'MCKF': [0, 2, 4, -2, 1, -4]}
+    lanes_of = {'GMCKF': [0, 2, 4, 1, -2, 8], 'KF': [0, 2, 4, -4, 8], 'IMCCKF': [0, 2, 4, -2, 8], 'MCKF': [0, 2, 4, -2, 1, -4]}
     shapes = {}
     for m in (8, 6, 2):                                            # 4, 3 and 1 features (BASELINE configs 2 and 1; the reference's tests/*_3_features)
         des = desired[:m]
@@ -84,6 +84,8 @@ def main():
         # round 4's launch options: MCKF trials cut into 1-16 segments (tuned two-lane kernel only; others ignore it), the latency mapping,
         # strict pinv on one case in eight
         opts = int(rng.integers(1, 17)) << 8 if (method == 'MCKF' and rng.random() < 0.7) else 0
+        if method == 'GMCKF' and m == 8 and lane == 2 and rng.random() < 0.5:      # RMCKF's segmented instantiation (two lanes per filter only)
+            opts = int(rng.integers(2, 17)) << 8
         if lane == 0 and rng.random() < 0.4:
             opts |= 2
         if rng.random() < 0.125:
