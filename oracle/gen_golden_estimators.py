@@ -4,13 +4,14 @@ bandwidth annealing the first generator exercises for RMCKF only.
 BUILD-CONTAINER ONLY (imports /root/reference through gen_golden.py; only the .npz vectors travel).  Every run is the UNMODIFIED reference's
 ``Experiment.run()`` (experiment.py:48-359) on the plant of SURVEY Appendix A, recorded as in gen_golden.py.
 
-    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the sixteen listed in main)
+    python oracle/gen_golden_estimators.py      # writes tests/golden/closed_{kf,imcckf,mckf}_*.npz (the eighteen listed in main)
 """
 import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+import numpy as np                                                    # noqa: E402
 import gen_golden as G                                                # noqa: E402
 
 
@@ -37,6 +38,23 @@ def main():
         G.DT, G.T_MAX, G.GAIN = dt, t_max, gain
         G.save_closed(name, meth, NT.ALPHA_STABLE, AS(1.5), 323456, x_stride=8, **kw)
     G.DT, G.T_MAX, G.GAIN = 0.05, 15, 0.2
+    # another servo target in the SAME scene: the discs stay where gen_golden.py puts them (goal pose -> DESIRED), desired_f moves.  RefPlant reads the
+    # module's DESIRED when it is built, so it is built under the scene's value and the run is made under the target's; the fixture carries both
+    scene = G.DESIRED.copy()
+    plant_init = G.RefPlant.__init__
+
+    def scene_init(self):
+        keep, G.DESIRED = G.DESIRED, scene
+        try:
+            plant_init(self)
+        finally:
+            G.DESIRED = keep
+    G.RefPlant.__init__ = scene_init
+    G.DESIRED = scene + np.array([12.0, -8.0, 12.0, -8.0, 12.0, -8.0, 12.0, -8.0])
+    G.save_closed('gmckf_target_shift', M.GMCKF, NT.ALPHA_STABLE, AS(1.5), 423456, x_stride=8, extra=dict(scene_desired=scene))
+    G.save_closed('kf_target_shift', M.KF, NT.ALPHA_STABLE, AS(2.0), 423459, x_stride=8, extra=dict(scene_desired=scene))
+    G.DESIRED = scene
+    G.RefPlant.__init__ = plant_init
     # other kernel bandwidths for the estimators with ONE weight per filter / per state entry
     G.save_closed('imcckf_sigma30_anneal', M.IMCCKF, NT.ALPHA_STABLE, AS(1.5), 423457, kernel_bw=30, annealing=True, x_stride=8)
     G.save_closed('mckf_sigma30', M.MCKF, NT.ALPHA_STABLE, AS(1.2), 423458, kernel_bw=30, x_stride=8)

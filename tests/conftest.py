@@ -36,6 +36,12 @@ def load_golden(name):
     return d
 
 
+def scene_desired(g):
+    """Features the fixture's SCENE projects onto at the goal pose (where the discs are): the servo target g['desired'] unless the fixture
+    moved the target inside the same scene (oracle/gen_golden_estimators.py, *_target_shift)."""
+    return g['scene_desired'] if 'scene_desired' in g else g['desired']
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, scene_desired
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def test_closed_loop_is_graph_capturable(uvs, method, segments, options):
     import torch
     K, T = 100, 96
     g, q0, noise = _inputs(uvs, T, K, 21)
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     fp = uvs.engine.make_params(8, 6, method, 10.0, True, 0.05, 15.0, 0.2, g['desired'], True, 2 if segments else 0, K)
     fp.reserved = (segments << 8) | options
     if segments:
@@ -96,7 +96,7 @@ def test_careful_second_pass_inside_a_graph(uvs):
     g, h = load_golden('rankdef_gmckf_rank4_product'), load_golden('closed_gmckf_a1p5')
     K, T = 120, 40
     sick = [0, 21]
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     meta, p = g['meta'], g['meta']['params']
     fp = uvs.engine.make_params(8, 6, meta['method'], p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'], g['desired'], False, 0, K)
     rng = np.random.default_rng(4)

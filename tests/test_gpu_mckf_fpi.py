@@ -6,7 +6,7 @@ same fixtures (trajectories AND passes per step)."""
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, rel_err
+from conftest import golden_names, load_golden, rel_err, scene_desired
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +41,7 @@ def _fp(uvs, g, lanes=0, steps=None):
 def test_closed_loop_matches_reference_fpi(uvs, name, lanes):
     g = load_golden(name)
     k = len(g['t'])
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     T = 3                                                                     # the same trial three times: lanes must agree bitwise
     out = uvs.engine.closed_loop(_fp(uvs, g, lanes), plant.to_struct(), _cuda(np.tile(g['q_start'], (T, 1))),
                                  _cuda(np.repeat(g['noise_full'][:, :, None], T, axis=2)), want=('x', 'err', 'q', 'f', 'dq'))
@@ -227,7 +227,7 @@ def test_infinite_sample_is_a_skipped_correction_for_mckf(uvs, lanes):
     K = 40
     noise = np.repeat(g['noise'][:K, :, None], 3, axis=2).copy()
     noise[11, 2, 1] = np.inf                                                  # trial 1 only
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     for method, k_fail in (('MCKF', 12), ('GMCKF', 11), ('KF', 11)):
         ref = c_oracle.closed_loop_batch(np.tile(g['q_start'], (3, 1)), noise.transpose(2, 0, 1), g['desired'], method, steps=K)
         assert ref['status'].tolist() == [0, 1, 0] and ref['k_done'].tolist() == [K, k_fail, K]
@@ -255,7 +255,7 @@ def test_segmented_trials_equal_whole_trials_on_reference_fixtures(uvs, name, se
     import torch
     g = load_golden(name)
     k = len(g['t'])
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     T = 70                                                                    # three wavefronts, the last one ragged
     q0, nz = _cuda(np.tile(g['q_start'], (T, 1))), _cuda(np.repeat(g['noise_full'][:, :, None], T, axis=2))
     base = _fp(uvs, g)

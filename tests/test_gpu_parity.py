@@ -4,7 +4,7 @@ import json
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, rel_err
+from conftest import golden_names, load_golden, rel_err, scene_desired
 
 pytestmark = pytest.mark.gpu
 
@@ -259,7 +259,7 @@ def test_closed_loop_matches_reference(uvs, name, lanes):
     g = load_golden(name)
     K = len(g['t'])
     fp = _fp(uvs, g, lanes)
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:, :, None]),
                                  want=('x', 'err', 'q', 'f', 'dq'))
     assert int(out['status'][0]) == int(g['status']) and int(out['k_done'][0]) == K
@@ -280,7 +280,7 @@ def test_closed_loop_matches_reference(uvs, name, lanes):
 def test_initial_guess_matches_reference(uvs):
     g = load_golden('closed_gmckf_a1p5_jitter')
     fp = _fp(uvs, g, steps=1)
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:1, :, None]), want=('x', 'f'))
     assert rel_err(out['x'].cpu().numpy()[0, :, 0], g['X'][0]) <= 1e-12      # step 0: H = 0 so X stays X0
     assert rel_err(out['f'].cpu().numpy()[0, :, 0], g['f'][0]) <= 1e-13
@@ -486,7 +486,7 @@ def test_non_finite_state_fails_the_trial_only(uvs):
     g = load_golden('closed_gmckf_a1p5')
     K, T, bad_step = 50, 6, 17
     fp = _fp(uvs, g, steps=K)
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     noise = np.repeat(g['noise'][:K, :, None], T, axis=2)
     noise[bad_step, 3, 2] = np.nan                                           # trial 2 sees a NaN measurement
     out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(np.tile(g['q_start'], (T, 1))), _cuda(noise), want=('err', 'x'))
@@ -502,7 +502,7 @@ def test_empty_and_degenerate_batches(uvs):
     and a ragged batch (not a multiple of the 32 trials of a wavefront) behave like slices of a bigger batch."""
     import ctypes as C
     g = load_golden('closed_gmckf_a1p5')
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     fp = _fp(uvs, g, steps=0)
     out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(np.tile(g['q_start'], (5, 1))), None, want=('err',))
     assert out['k_done'].tolist() == [0] * 5 and out['status'].tolist() == [0] * 5 and float(out['stats'].abs().max()) == 0.0
@@ -569,7 +569,7 @@ def test_full_size_batch_properties(uvs):
     meta = g['meta']
     T, K = 65536, 299
     fp = _fp(uvs, g)
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     gen = torch.Generator(device='cuda').manual_seed(11)
     noise = torch.empty((K, 8, T), dtype=torch.float64, device='cuda')
     noise.cauchy_(generator=gen)                                             # impulsive, like alpha = 1
@@ -869,7 +869,7 @@ def test_latency_option_picks_four_lanes_for_small_batches_and_stays_inside_the_
     import ctypes as C
     g = load_golden('closed_gmckf_a1p5')
     K = len(g['t'])
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     lanes = lambda fp, T: int(uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp), C.byref(plant), T))      # noqa: E731
     fp = _fp(uvs, g)
     assert [lanes(fp, T) for T in (1, 8192, 16384, 16385, 65536)] == [4, 4, 4, 2, 2]      # by default too: the four-lane kernels with the two-lane bits
@@ -908,7 +908,7 @@ def test_small_batches_run_on_four_lanes_with_the_two_lane_bits(uvs, method):
     K = 120
     for T, anneal, tilt in ((1, False, False), (23, True, False), (200, False, False), (77, True, True)):
         rng = np.random.default_rng(T)
-        plant = uvs.SyntheticPlant.ur10(g['desired'])
+        plant = uvs.SyntheticPlant.ur10(scene_desired(g))
         if tilt:
             plant.alpha = np.asarray(plant.alpha, float).copy()
             plant.alpha[2] += 0.05                                            # no longer axis-aligned: the general chain code
@@ -974,7 +974,7 @@ def test_segmented_rmckf_launch_is_bit_identical_to_whole_trials(uvs):
     import ctypes as C
     import torch
     g = load_golden('closed_gmckf_a1p5')
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     K, T = 120, 150
     rng = np.random.default_rng(9)
     q0 = np.tile(g['q_start'], (T, 1)); q0[:, :3] += rng.uniform(-0.2, 0.1, (T, 3))

@@ -7,7 +7,7 @@ are not touched by the second pass, and no internal status leaks out."""
 import numpy as np
 import pytest
 
-from conftest import RANKDEF_CMD_TOL, golden_names, load_golden, rel_err
+from conftest import RANKDEF_CMD_TOL, golden_names, load_golden, rel_err, scene_desired
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +85,7 @@ def test_strict_pinv_closed_loop_on_the_blind_fixture(uvs):
     the first step on (the reference's truncated command is ~1e-5 rad/s, the plain least-squares one is not)."""
     g = load_golden(BLIND)
     K = len(g['t'])
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     args = (plant, _cuda(np.tile(g['q_start'], (3, 1))), _cuda(np.repeat(g['noise'][:, :, None], 3, axis=2)), _cuda(np.tile(g['X'][0], (3, 1))))
     strict = uvs.engine.closed_loop(_fp(uvs, g, 0, strict=True), *args, want=('x', 'err', 'q', 'dq'))
     assert strict['status'].cpu().tolist() == [0] * 3 and strict['k_done'].cpu().tolist() == [K] * 3
@@ -101,7 +101,7 @@ def test_strict_pinv_agrees_with_the_fast_path_on_healthy_trials(uvs):
     g = load_golden('closed_gmckf_a1p5')
     K = len(g['t'])
     meta, p = g['meta'], g['meta']['params']
-    plant = uvs.SyntheticPlant.ur10(g['desired']).to_struct()
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     outs = []
     for strict in (False, True):
         fp = uvs.engine.make_params(8, 6, 'GMCKF', p['kernel_bw'], p['annealing'], meta['dt'], meta['t_max'], meta['gain'], g['desired'], True, 0)
@@ -117,7 +117,7 @@ def test_strict_pinv_agrees_with_the_fast_path_on_healthy_trials(uvs):
 def test_closed_loop_matches_reference_on_rank_deficient_jacobians(uvs, name, lanes):
     g = load_golden(name)
     K = len(g['t'])
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     out = uvs.engine.closed_loop(_fp(uvs, g, lanes), plant.to_struct(), _cuda(g['q_start'][None]), _cuda(g['noise'][:, :, None]),
                                  _cuda(g['X'][0][None]), want=('x', 'err', 'q', 'dq'))
     assert int(out['status'][0]) == 0 and int(out['k_done'][0]) == K
@@ -132,7 +132,7 @@ def test_second_pass_leaves_healthy_trials_alone(uvs):
     g, h = load_golden('rankdef_gmckf_rank4_product'), load_golden('closed_gmckf_a1p5')
     K, T = 120, 160
     sick = [3, 40]
-    plant = uvs.SyntheticPlant.ur10(g['desired'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g))
     rng = np.random.default_rng(5)
     x0 = np.tile(h['X'][0], (T, 1)) * (1 + 0.02 * rng.standard_normal((T, 1)))
     noise = rng.standard_t(3, size=(K, 8, T))
