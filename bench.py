@@ -288,7 +288,7 @@ def side_config(config, torch, uvs_amd, engine, batch, dev, trials=None, reps=5,
         cfg['estimator']['estimator_params']['annealing'] = True
         cfg['experiments']['epoch'] = T
         plan = batch.plan_trials(cfg, cells=[0.1])
-        noise = batch.device_noise(cfg, plan, 0, T, K, dev)
+        noise = batch.device_noise(cfg, plan, 0, T, K, dev, share=False)
         q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
         fp = engine.make_params(8, 6, 'GMCKF', 10, True, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, lanes)
         plant, x0 = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct(), None
@@ -420,9 +420,19 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     nt = uvs_amd.NoiseType.ALPHA_STABLE
     seeds_dev = torch.as_tensor(np.asarray(plan.seed, dtype=np.uint64).view(np.int64), device=dev)     # every cell's seeds, uploaded once
 
+    S = T + uvs_amd.noise_device.SEED_STEP * (M - 1)              # distinct streams of a cell: seeds seed0 + c T ... + T + 70 (noise.py:70, main.py:139)
+    shared = [torch.empty((K, S), dtype=torch.float64, device=dev) for _ in range(2)]
+    assert uvs_amd.noise_device.shares_streams(nt, False, plan.seed[:T])
+    dense_gen = [False]                                           # True: every trial's 8 streams generated separately (round 4's path), for the comparison
+
     def gen(c, buf):
+        """Noise of cell c; returns the [step][feature][trial] tensor the closed loop reads (buf itself, or the overlapping view of shared[.])."""
         params = dict(alpha=float(cells[c]), beta=0, gamma=1, delta=0)
-        uvs_amd.noise_device.generate(nt, params, seeds_dev[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
+        if dense_gen[0]:
+            uvs_amd.noise_device.generate(nt, params, seeds_dev[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
+            return buf
+        slot = 0 if buf is noise[0] else 1
+        return uvs_amd.noise_device.generate_shared(nt, params, int(plan.seed[c * T]), T, M, K, out=shared[slot], device=dev)[1]
 
     def loop(c, buf, slot, csv=False):
         # csv: the per-step streams results.csv holds (main.py:152-194: error, q, f; the camera pose follows from q, the noise is the input) --
@@ -440,14 +450,19 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
 
     def serial():
         for c in range(len(cells)):
-            gen(c, noise[0])
-            loop(c, noise[0], 0)
+            loop(c, gen(c, noise[0]), 0)
         torch.cuda.synchronize()
+
+    def serial_dense():
+        dense_gen[0] = True
+        try:
+            serial()
+        finally:
+            dense_gen[0] = False
 
     def serial_csv():
         for c in range(len(cells)):
-            gen(c, noise[0])
-            loop(c, noise[0], 0, csv=True)
+            loop(c, gen(c, noise[0]), 0, csv=True)
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream(device=dev)
@@ -460,15 +475,15 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
             with torch.cuda.stream(side):
                 if c >= 2:
                     side.wait_event(freed[c - 2])                  # the buffer's previous cell has been consumed
-                gen(c, noise[c % 2])
+                view = gen(c, noise[c % 2])
                 ready[c].record(side)
             main.wait_event(ready[c])
-            loop(c, noise[c % 2], c % 2)
+            loop(c, view, c % 2)
             freed[c].record(main)
         torch.cuda.synchronize()
 
     out = {}
-    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped), ('one_stream_csv_streams', serial_csv)):
+    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped), ('one_stream_csv_streams', serial_csv), ('one_stream_every_stream_generated', serial_dense)):
         fn()                                                       # warm-up (allocator, tables)
         t0 = time.perf_counter()
         fn()
@@ -479,7 +494,7 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     # the pieces on their own (events on one stream), for the breakdown
     ev = lambda: torch.cuda.Event(enable_timing=True)             # noqa: E731
     a, b, c_, d = ev(), ev(), ev(), ev()
-    a.record(); gen(5, noise[0]); b.record(); loop(5, noise[0], 0); c_.record()
+    a.record(); v5 = gen(5, noise[0]); b.record(); loop(5, v5, 0); c_.record()
     torch.cuda.synchronize()
     out['breakdown_one_cell_ms'] = {'seeding_and_noise_generation': a.elapsed_time(b), 'closed_loop_kernel_and_row_copy': b.elapsed_time(c_)}
     out.update(workload=f'the reference sweep of main.py:104-148: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), X+err+q logged on the device, '
@@ -670,10 +685,10 @@ def main():
         if args.host_noise:
             noise = torch.as_tensor(noise_host, device=dev)       # PCIe upload, outside the timed region
         else:                                                     # NoiseProfiler-compatible streams generated on the GPU
-            noise = batch.device_noise(cfg, plan, lo, hi, K, dev)          # first call: + one-time table upload / torch warm-up
+            noise = batch.device_noise(cfg, plan, lo, hi, K, dev, share=False)          # first call: + one-time table upload / torch warm-up
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            noise = batch.device_noise(cfg, plan, lo, hi, K, dev)          # what one more sweep cell costs
+            noise = batch.device_noise(cfg, plan, lo, hi, K, dev, share=False)          # what one more sweep cell costs
             torch.cuda.synchronize()
             gen_s = time.perf_counter() - t1
         if args.layout != 'kct':                                  # generated as [step][comp][trial]
@@ -779,7 +794,7 @@ def main():
         plan_s = batch.plan_trials(cfg_s, cells=[ALPHA])
         lo_s, hi_s = dist.shard_range(len(plan_s), rank, world)
         Ts = hi_s - lo_s
-        noise_s = batch.device_noise(cfg_s, plan_s, lo_s, hi_s, K, dev)
+        noise_s = batch.device_noise(cfg_s, plan_s, lo_s, hi_s, K, dev, share=False)
         q0_s = torch.as_tensor(plan_s.q_start[lo_s:hi_s].copy(), device=dev)
         bufs_s = {k: engine.alloc_stream(Ts, K, c, 'kct', dev, zero=True) for k, c in (('x', M * N), ('err', M), ('q', N))}
         stats_s = torch.zeros((Ts, 3), dtype=torch.float64, device=dev)
@@ -869,7 +884,7 @@ def main():
                 fp = engine.make_params(M, N, meth, fp_head.kernel_bw, bool(fp_head.annealing), fp_head.dt, fp_head.dt * fp_head.k_max, fp_head.gain,
                                         list(fp_head.desired)[:M], bool(fp_head.initial_guess), args.lanes)
                 if alpha != ALPHA:
-                    noise = batch.device_noise(cfg1, plan1, lo, hi, K, dev)
+                    noise = batch.device_noise(cfg1, plan1, lo, hi, K, dev, share=False)
                 ms = []
                 for i in range(2 + 5):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -62,6 +62,10 @@ enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
  * UVS_OPT_LATENCY: use the plain four-lane kernels there instead (their own summation order: another 3-13 % faster -- 0.88 ms -- and results
  *   that differ from the default mapping in the last bits; same oracle gates). */
 #define UVS_OPT_LATENCY 2
+/* UVS_OPT_DIAG_DROP_SEG_FLAG (testing only): in a segmented launch the first segment of every trial chunk does not publish its hand-over
+ *   counter, so the chunk's second segment runs out its spin budget (~65 ms) and takes the fallback -- recompute the trial from step 0 --
+ *   that keeps segmented launches deadlock-free whatever the dispatcher does.  Results are bit-identical; tests/test_gpu_mckf_fpi.py forces it. */
+#define UVS_OPT_DIAG_DROP_SEG_FLAG 4
 
 /* Strided view of a [trial][step][component] array of doubles. */
 typedef struct uvs_view {
@@ -89,8 +93,8 @@ typedef struct uvs_filter_params {
     double reg;                 /* 0.001**2 added to Cy before inversion (:280)                     */
     double fpi_threshold;       /* MCKF fixed-point stop test (:38, :215)                           */
     int32_t fpi_epoch_max;      /* MCKF iteration cap; reaching it skips the correction (:39, :246) */
-    int32_t reserved;           /* option bits, 0 = defaults.  bit 0: UVS_OPT_STRICT_PINV, bit 1: UVS_OPT_LATENCY (both  */
-                                /* below).  bits 8-15: segments per MCKF trial for uvs_rmckf_closed_loop_ws_f64 (0 =       */
+    int32_t reserved;           /* option bits, 0 = defaults.  bit 0: UVS_OPT_STRICT_PINV, bit 1: UVS_OPT_LATENCY, bit 2:  */
+                                /* UVS_OPT_DIAG_DROP_SEG_FLAG (above).  bits 8-15: segments per MCKF trial for uvs_rmckf_closed_loop_ws_f64 (0 =       */
                                 /* library's choice); all other bits must be 0                                             */
     double desired[UVS_MAX_M];  /* desired_f (:21)                                                  */
 } uvs_filter_params;
@@ -252,6 +256,19 @@ int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void 
  * exponential, which costs up to ~40 ulp in the far tails).
  */
 int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream);
+
+/*
+ * The same streams without their redundancy.  NoiseProfiler seeds generator i of a trial with seed + 10 i (noise.py:70) and the Monte-Carlo
+ * driver gives trial t the seed seed0 + t (main.py:137-139): for the types with one generator per feature (WHITE_NOISE, ALPHA_STABLE, UNIFORM)
+ * and no outlier hold, feature i + 1 of trial t is the very stream of feature i of trial t + 10, so T consecutive trials hold only
+ * S = T + 10 (m - 1) distinct streams.  This call generates stream s = the getNoise() sequence of ONE generator in state states[s]
+ * (PCG64(seed0 + s), uvs_pcg64_seed_u64) into out[s * stream_stride + k * step_stride], k < np->steps (np->m is ignored, np->hold_cnt must
+ * be 0); the closed loop then reads the noise of trial t, feature i through the view {out, trial_stride = stream_stride,
+ * step_stride, comp_stride = 10 * stream_stride}.  Values are bit-identical to uvs_noise_generate_f64's: 1/m of the generator work and of
+ * the buffer (BASELINE config 2: 0.16 GB instead of 1.25 GB per cell).
+ */
+int uvs_noise_generate_streams_f64(const uvs_noise_params *np, int64_t S, const uint64_t *states, const double *zig,
+                                   double *out, int64_t stream_stride, int64_t step_stride, void *stream);
 
 /*
  * Which instantiation uvs_noise_generate_f64 launches for these parameters (host-side query, no GPU work): 0 = the kernel of np->type,

@@ -300,6 +300,40 @@ def test_segmented_mixed_batch_is_bit_identical(uvs, thr, cap, segments):
     assert torch.equal(a['stats'][ok].view(torch.int64), b['stats'][ok].view(torch.int64))
 
 
+@pytest.mark.parametrize('method,segments', [('MCKF', 4), ('GMCKF', 3)])
+def test_lost_hand_over_falls_back_to_recomputation(uvs, method, segments):
+    """The hand-over relies on in-order workgroup dispatch; if a predecessor's counter never arrives, a later segment recomputes the trial from
+    step 0 after its spin budget (~65 ms, csrc/rmckf_device.hpp kSegSpinMax) -- never a hang.  UVS_OPT_DIAG_DROP_SEG_FLAG withholds every chunk's
+    first counter: the launch must still finish promptly and reproduce the whole-trial launch bit for bit."""
+    import time
+    import torch
+    import bench
+    desired = bench.config2()['experiments']['desired_f']
+    T, K = 150, 90
+    q0, noise = _mixed_batch(np.random.default_rng(78), T, K)
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    outs = []
+    for n, drop in ((1, 0), (segments, 0), (segments, 4)):
+        fp = uvs.engine.make_params(8, 6, method, 10.0, False, 0.05, 15.0, 0.2, desired, True, 2, K, 1e-3, 1000)
+        fp.reserved = (n << 8) | drop
+        assert uvs.lib().uvs_rmckf_closed_loop_segments(fp, plant, T) == n
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs.append(uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q')))
+        torch.cuda.synchronize()
+        outs[-1]['wall'] = time.perf_counter() - t0
+    a, b, c = outs
+    assert c['wall'] > 0.03, 'the diagnostic bit did not take the fallback (a hand-over that waits out its budget lasts > 30 ms)'
+    assert c['wall'] < 2.0, 'fallback after the spin budget must come within a watchdog\'s patience'
+    live = torch.arange(K, device='cuda')[:, None, None] < a['k_done'][None, None, :]
+    for other in (b, c):
+        assert torch.equal(a['status'], other['status']) and torch.equal(a['k_done'], other['k_done'])
+        for key in ('x', 'err', 'q'):
+            assert torch.equal(torch.where(live, a[key], 0.0).view(torch.int64), torch.where(live, other[key], 0.0).view(torch.int64)), key
+        ok = a['status'] == 0
+        assert torch.equal(a['stats'][ok].view(torch.int64), other['stats'][ok].view(torch.int64))
+
+
 def test_workspace_too_small_or_absent_runs_whole_trials(uvs):
     """The workspace is an offer: NULL or too small simply runs unsegmented (same bits); a misaligned pointer is an argument error."""
     import ctypes as C

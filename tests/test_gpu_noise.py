@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 # streams built only from PCG64 doubles, the ziggurat normal and +,*: bit-identical to numpy (a tail sample may differ by an ulp)
 EXACT = {'noise_white', 'noise_white_m2', 'noise_mixture', 'noise_mixture_hold', 'noise_bimodal', 'noise_bimodal_hold', 'noise_alpha2p0',
-         'noise_uniform_jitter'}
+         'noise_uniform_jitter', 'noise_white_seed_plus10', 'noise_uniform_jitter_seed_plus10'}
 
 
 @pytest.fixture(scope='module')
@@ -122,3 +122,76 @@ def test_symmetric_stable_fast_path_and_its_gate(uvs, alpha):
     assert finite.mean() > 0.999 and np.array_equal(np.isfinite(dev), finite)
     rel = np.abs(dev[finite] - host[finite]) / np.abs(host[finite])
     assert rel.max() <= 2e-13, (alpha, rel.max())
+
+
+# ---------------------------------------------------------------------------------------------- shared streams (uvs_noise_generate_streams_f64)
+@pytest.mark.parametrize('kind,params', [
+    ('ALPHA_STABLE', dict(alpha=1.5, beta=0, gamma=1, delta=0)), ('ALPHA_STABLE', dict(alpha=1.0, beta=0, gamma=1, delta=0)),
+    ('ALPHA_STABLE', dict(alpha=2.0, beta=0, gamma=1, delta=0)), ('ALPHA_STABLE', dict(alpha=1.3, beta=0.4, gamma=2.0, delta=1.0)),
+    ('WHITE_NOISE', dict(std=1.0)), ('UNIFORM', {})])
+@pytest.mark.parametrize('T', [1, 70, 4099])
+def test_shared_streams_are_the_per_trial_streams(uvs, kind, params, T):
+    """T consecutive seeds, no hold: T + 70 streams generated once and read through the overlapping (S, 10, 1)-strided view carry the very
+    bits of the 8 T streams generated per trial (noise.py:70 + main.py:137-139)."""
+    import torch
+    nt = uvs.NoiseType[kind]
+    K, m, seed0 = 61, 8, 123456
+    seeds = seed0 + np.arange(T)
+    assert uvs.noise_device.shares_streams(nt, False, seeds) and not uvs.noise_device.shares_streams(nt, True, seeds)
+    dense = uvs.noise_device.generate(nt, params, seeds, m, K)
+    buf, view = uvs.noise_device.generate_shared(nt, params, seed0, T, m, K)
+    assert buf.shape == (K, T + 70) and view.shape == dense.shape == (K, m, T)
+    assert torch.equal(view.contiguous().view(torch.int64), dense.view(torch.int64))
+
+
+def test_shared_streams_reproduce_the_reference_fixtures(uvs):
+    g0, g1 = load_golden('noise_alpha1p5'), load_golden('noise_alpha1p5_seed_plus10')
+    K = len(g0['values'])
+    _, view = uvs.noise_device.generate_shared(uvs.NoiseType.ALPHA_STABLE, g0['meta']['noise_params'], g0['meta']['seed'], 11, 8, K)
+    got = view.cpu().numpy()                                                  # [K][8][11]
+    assert np.allclose(got[:, :, 0], g0['values'], rtol=2e-13, atol=0) and np.allclose(got[:, :, 10], g1['values'], rtol=2e-13, atol=0)
+
+
+def test_streams_entry_point_rejects_what_does_not_alias(uvs):
+    import ctypes as C
+    import torch
+    buf = torch.zeros((4, 80), dtype=torch.float64, device='cuda')
+    st = torch.zeros((80, 4), dtype=torch.int64, device='cuda')
+    zig = uvs.noise_device._zig('cuda')
+    for kind, hold in (('GAUSSIAN_MIXTURE', 0), ('GAUSSIAN_BIMODAL', 0), ('ALPHA_STABLE', 10)):
+        q = uvs.noise_device.make_noise_params(uvs.NoiseType[kind], dict(std=1.0, mean=5.0, rho=0.1, alpha=1.5, beta=0, gamma=1, delta=0), 8, 4, hold > 0, hold)
+        assert uvs.lib().uvs_noise_generate_streams_f64(C.byref(q), 80, st.data_ptr(), zig.data_ptr(), buf.data_ptr(), 1, 80, None) == -1
+    assert not uvs.noise_device.shares_streams(uvs.NoiseType.GAUSSIAN_MIXTURE, False, [5, 6, 7])
+    assert not uvs.noise_device.shares_streams(uvs.NoiseType.ALPHA_STABLE, False, [5, 7, 8])          # seeds not consecutive
+
+
+@pytest.mark.parametrize('T', [4099, 65536])
+def test_sweep_rows_do_not_change_with_shared_streams(uvs, T):
+    """The 12-cell sweep of main.py:104-148 with the noise of every cell generated once per distinct seed: per-trial [ISE, IAE, ITAE, status,
+    k_done] rows and the error stream bit-identical to the sweep that generates all 8 T streams of a cell (VERDICT r4 #2)."""
+    import torch
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = T
+    plan = uvs.batch.plan_trials(cfg)
+    assert len(plan.cells) == 12
+    K = len(uvs.engine.loop_clock(0.05, 15))
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
+    plant = uvs.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    failed = 0
+    for c in range(12 if T < 10000 else 3):                                  # (the full-size run checks three cells: Cauchy, 1.09, 1.18)
+        lo, hi = c * T, (c + 1) * T
+        q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device='cuda')
+        outs = []
+        for share in (False, True):
+            noise = uvs.batch.device_noise(cfg, plan, lo, hi, K, 'cuda', share=share)
+            assert (noise.stride(2) == 1 and noise.stride(1) == 10) == share
+            outs.append(uvs.engine.closed_loop(fp, plant, q0, noise, want=('err',)))
+            del noise
+        a, b = outs
+        assert torch.equal(a['status'], b['status']) and torch.equal(a['k_done'], b['k_done'])
+        assert torch.equal(a['stats'].view(torch.int64), b['stats'].view(torch.int64))
+        assert torch.equal(a['err'].view(torch.int64), b['err'].view(torch.int64))
+        failed += int((a['status'] != 0).sum())
+        del outs, a, b
+    assert failed < 0.01 * T

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 CLOSED = golden_names('closed_')                                             # KF / MCKF / IMCCKF / GMCKF fixtures
 CHAOTIC = {'closed_gmckf_mix_anneal_hold'}                                   # feedback amplifies rounding
 LANES_86 = (1, 2, 4, -1, -2, -4, 8, -8)  # 1, 2, 4: tuned kernel (closed loop); 8: the wide kernel's one-row-per-lane DH instantiation (closed loop); negative: generic template with |L| lanes
-LANES_CLOSED = LANES_86
+LANES_CLOSED = (0,) + LANES_86          # 0: the library's own choice (small batches: the four-lane kernels with the two-lane bits)
 
 
 @pytest.fixture(scope='module')

@@ -348,3 +348,26 @@ def test_noise_kernel_variant_gate(uvs):
         assert abs((1 - a) / a) * 2e-16 <= 2e-14 * np.cos(abs(1 - a) * np.pi / 2)
     assert 0.05 < lo < 0.2 and 1.995 < hi < 2.0
 
+
+
+@pytest.mark.parametrize('base,shifted', [('noise_alpha1p5', 'noise_alpha1p5_seed_plus10'), ('noise_alpha1p0', 'noise_alpha1p0_seed_plus10'),
+                                          ('noise_white', 'noise_white_seed_plus10'), ('noise_uniform_jitter', 'noise_uniform_jitter_seed_plus10')])
+def test_reference_streams_alias_across_trials(uvs, base, shifted):
+    """What the sweep's shared noise buffer rests on, pinned on the reference's own output (oracle/gen_golden.py ran NoiseProfiler at seed and
+    at seed + 10): generator i is PCG64(seed + 10 i) (noise.py:70), so feature i + 1 of the trial seeded s is, bit for bit, feature i of the
+    trial seeded s + 10 -- and the driver seeds trial t with seed + t (main.py:137-139)."""
+    a, b = load_golden(base), load_golden(shifted)
+    assert b['meta']['seed'] == a['meta']['seed'] + 10 and not a['meta']['hold'] and a['meta']['noise_params'] == b['meta']['noise_params']
+    assert np.array_equal(a['values'][:, 1:], b['values'][:, :-1]) and not np.array_equal(a['values'][:, 0], b['values'][:, 0])
+    nt = uvs.NoiseType[a['meta']['noise_type']]
+    seeds = a['meta']['seed'] + np.arange(11)
+    assert uvs.noise_device.shares_streams(nt, False, seeds)
+    assert not uvs.noise_device.shares_streams(nt, True, seeds)                        # the hold couples the two features of a pair (noise.py:82-116)
+    assert not uvs.noise_device.shares_streams(nt, False, seeds[::2])                  # only consecutive seeds line up with the stride 10
+    # the host generator, walked the same way: [step][S] streams, entry (k, i, t) of the dense batch = stream t + 10 i
+    m, K = a['meta']['m'], 40
+    dense = uvs.noise_batch(nt, a['meta']['noise_params'], seeds, m, K)                   # (T, K, m)
+    S = len(seeds) + 10 * (m - 1)
+    streams = uvs.noise_batch(nt, a['meta']['noise_params'], a['meta']['seed'] + np.arange(S), m, K)[:, :, 0]     # feature 0 of S trials
+    for i in range(m):
+        assert np.array_equal(dense[:, :, i], streams[10 * i:10 * i + len(seeds)])

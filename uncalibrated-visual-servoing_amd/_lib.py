@@ -70,6 +70,7 @@ SYMBOLS = {
     'uvs_stats_reduce_f64': (C.c_int, [_I64, _I32, _I32, View, _VP, _VP, _VP, _VP]),
     'uvs_debug_math_f64': (C.c_int, [_I32, _I64, _VP, _VP, _VP]),
     'uvs_noise_generate_f64': (C.c_int, [C.POINTER(NoiseParams), _I64, _VP, _VP, View, _VP]),
+    'uvs_noise_generate_streams_f64': (C.c_int, [C.POINTER(NoiseParams), _I64, _VP, _VP, _VP, _I64, _I64, _VP]),
     'uvs_noise_kernel_variant': (C.c_int, [C.POINTER(NoiseParams)]),
     'uvs_pcg64_seed_u64': (C.c_int, [_I64, _VP, _VP, _VP]),
 }

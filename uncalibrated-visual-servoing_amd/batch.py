@@ -109,15 +109,23 @@ class BatchResult:
     seconds: float = 0.0
 
 
-def device_noise(cfg, plan, lo, hi, steps, device='cuda'):
-    """Noise streams of trials lo..hi generated on the GPU (noise_device.py), [step][feature][trial]."""
+def device_noise(cfg, plan, lo, hi, steps, device='cuda', share=True):
+    """Noise streams of trials lo..hi generated on the GPU (noise_device.py), [step][feature][trial].  ``share``: where the trials' streams
+    alias (noise_device.shares_streams) generate each distinct stream once and return an overlapping view."""
     nz = cfg['noise']
     noise_type = NoiseType[nz['type']]
     m = len(cfg['experiments']['desired_f'])
     hold_cnt = int(nz['hold_time'] / cfg['experiments']['dt'])      # main.py:137
     key = 'alpha' if noise_type == NoiseType.ALPHA_STABLE else 'rho'
-    out = engine.alloc_stream(hi - lo, steps, m, 'kct', device)
     torch = engine._torch()
+    cells_here = np.unique(plan.cell[lo:hi])
+    if share and len(cells_here) == 1 and noise_device.shares_streams(noise_type, nz['hold'], plan.seed[lo:hi]):
+        # one cell, consecutive seeds, no hold: the T + 70 distinct streams once, read through an overlapping [step][feature][trial] view
+        # (main.py:137-139 + noise.py:70; a shard's rank generates seeds lo ... hi + 70) -- bit-identical to the per-trial generation below
+        params = dict(nz['noise_params'])
+        params[key] = float(plan.cells[cells_here[0]])
+        return noise_device.generate_shared(noise_type, params, int(plan.seed[lo]), hi - lo, m, steps, device=device)[1]
+    out = engine.alloc_stream(hi - lo, steps, m, 'kct', device)
     seeds_dev = torch.as_tensor(np.ascontiguousarray(plan.seed[lo:hi], dtype=np.uint64).view(np.int64), device=device)   # one upload for the shard
     for c in np.unique(plan.cell[lo:hi]):
         idx = np.nonzero(plan.cell[lo:hi] == c)[0]                  # cells are contiguous runs of trials (main.py:121-127)

@@ -70,6 +70,7 @@ bool replay_f32(int m, int n, int method, int64_t T, hipStream_t s, const uvs::R
 void stats(long long T, int K, int m, uvs::View err, const double *t, const int *k_done, double *stats, hipStream_t s);
 void debug_math(int which, long long n, const double *x, double *y, hipStream_t s);
 void noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s);
+void noise_streams(const uvs_noise_params &np, long long S, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s);   // one generator per stream, no hold
 int noise_variant(const uvs_noise_params &np);                       // 0 = kernel of np.type, 1 = beta = 0 alpha-stable specialisation
 void pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s);
 // p[0..n) = v as a KERNEL: inside a captured graph a memset node in front of the closed-loop kernel was seen to land late on every other replay

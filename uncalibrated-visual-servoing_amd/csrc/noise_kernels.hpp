@@ -251,4 +251,26 @@ __global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_kernel(const NoiseArgs
     }
 }
 
+// One generator per lane, no hold: stream s is the getNoise() sequence of a feature whose generator is PCG64 in state A.states[s] -- for the
+// noise types with one generator per feature (noise.py:66-70: WHITE_NOISE, ALPHA_STABLE, UNIFORM).  The Monte-Carlo driver seeds feature i of
+// trial t with seed0 + t + 10 i (main.py:137-139 + noise.py:70), so feature i + 1 of trial t IS feature i of trial t + 10: a cell of T trials
+// holds only T + 10 (m - 1) distinct streams, and the closed loop reads them through a view with trial_stride 1, comp_stride 10 (SURVEY.md
+// section 7; uvs_noise_generate_streams_f64).  Rows are stream-fastest: a wavefront writes 512 contiguous bytes per step.
+template <int TYPE>
+__global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_streams_kernel(const NoiseArgs A) {
+    static_assert(TYPE == UVS_NOISE_WHITE || TYPE == UVS_NOISE_ALPHA_STABLE || TYPE == UVS_NOISE_UNIFORM || TYPE == kNoiseStableSymmetric,
+                  "one generator per feature");
+    const uvs_noise_params &p = A.np;
+    const long long s = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (s >= A.T) return;
+    Pcg64 g[1], sel;
+    g[0].load(A.states + s * 4);
+    sel.sh = sel.sl = sel.ih = sel.il = 0;                    // unused
+    double *o = A.out.p + s * A.out.st;
+    for (int k = 0; k < p.steps; ++k) {
+        *o = draw<TYPE>(p, g, sel, A.zig);
+        o += A.out.sk;
+    }
+}
+
 }  // namespace uvs

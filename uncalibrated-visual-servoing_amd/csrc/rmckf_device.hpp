@@ -130,7 +130,10 @@ struct ClosedArgs {
 constexpr int seg_state_doubles(int M, int N, int L) {
     return 3 * N + N + (M / L) + 1 + (M / L) * (N * (N + 1) / 2) + (M / L) * N + 3 * (M / L) + 1;
 }
-constexpr int kSegSpinMax = 1 << 22;            // x ~1 us of s_sleep: after ~4 s without its predecessor a segment recomputes the trial from step 0 instead
+// x ~1 us of s_sleep 32: after ~65 ms without its predecessor (a segment lasts < 1 ms) a later segment recomputes the trial from step 0 instead.
+// Short on purpose: should in-order dispatch ever not hold (another dispatcher policy, a debugger, a partitioned GPU) the launch degrades to
+// recomputation within a watchdog's patience instead of sitting seconds per segment (round 4: 1 << 22, ~4 s).
+constexpr int kSegSpinMax = 1 << 16;
 
 struct ReplayArgs {
     uvs_filter_params fp;

@@ -1511,7 +1511,9 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             seg_state(std::true_type{});
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every write-through store of the wavefront has been acknowledged before ...
             asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&A.ws_flags[chunk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the counter moves
+            // (UVS_OPT_DIAG_DROP_SEG_FLAG: segment 0 keeps its counter to itself, so every second segment runs out its spin budget and recomputes -- tests only)
+            if (lane == 0 && !((A.fp.reserved & UVS_OPT_DIAG_DROP_SEG_FLAG) && seg == 0))
+                __hip_atomic_store(&A.ws_flags[chunk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the counter moves
 #ifdef UVS_WAVE_TIMES
             if (lane == 0 && A.stats) {
                 unsigned long long wt_last;

@@ -47,6 +47,21 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
     }
 }
 
+void uvs_launch::noise_streams(const uvs_noise_params &np, long long S, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+    uvs::NoiseArgs A{np, S, states, zig, out};
+    const dim3 g((unsigned)((S + 63) / 64));
+    switch (np.type) {
+        case UVS_NOISE_WHITE: hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_WHITE>, g, dim3(64), 0, s, A); break;
+        case UVS_NOISE_ALPHA_STABLE:
+            if (noise_variant(np) == 1)
+                hipLaunchKernelGGL(uvs::noise_streams_kernel<uvs::kNoiseStableSymmetric>, g, dim3(64), 0, s, A);
+            else
+                hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A);
+            break;
+        default: hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_UNIFORM>, g, dim3(64), 0, s, A); break;
+    }
+}
+
 int uvs_launch::noise_variant(const uvs_noise_params &np) {
     return (np.type == UVS_NOISE_ALPHA_STABLE && uvs::stable_symmetric_fast(np)) ? 1 : 0;
 }

@@ -327,6 +327,16 @@ int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t
     return check_launch("noise_kernel");
 }
 
+int uvs_noise_generate_streams_f64(const uvs_noise_params *np, int64_t S, const uint64_t *states, const double *zig, double *out, int64_t stream_stride,
+                                   int64_t step_stride, void *stream) {
+    if (!np || S <= 0 || !states || !zig || !out || np->steps < 0) return fail(UVS_ERR_ARG, "%s", "bad noise_generate_streams arguments");
+    if (np->type != UVS_NOISE_WHITE && np->type != UVS_NOISE_ALPHA_STABLE && np->type != UVS_NOISE_UNIFORM)
+        return fail(UVS_ERR_ARG, "%s", "noise streams: only the types with one generator per feature (WHITE_NOISE, ALPHA_STABLE, UNIFORM)");
+    if (np->hold_cnt != 0) return fail(UVS_ERR_ARG, "%s", "noise streams: the outlier hold couples the two features of a pair; use uvs_noise_generate_f64");
+    noise_streams(*np, (long long)S, (const unsigned long long *)states, zig, uvs::View{out, stream_stride, step_stride, 0}, (hipStream_t)stream);
+    return check_launch("noise_streams_kernel");
+}
+
 int uvs_noise_kernel_variant(const uvs_noise_params *np) {
     if (!np || np->type < UVS_NOISE_WHITE || np->type > UVS_NOISE_UNIFORM) return fail(UVS_ERR_ARG, "%s", "bad noise parameters");
     return noise_variant(*np);
