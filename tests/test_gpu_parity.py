@@ -832,7 +832,7 @@ def test_pitched_streams_give_the_same_bits(uvs, method, monkeypatch):
     res = {}
     for pad in ('0', '37'):
         monkeypatch.setenv('UVS_ROW_PAD', pad)
-        noise = uvs.batch.device_noise(cfg, plan, 0, len(plan), fp.steps, 'cuda')
+        noise = uvs.batch.device_noise(cfg, plan, 0, len(plan), fp.steps, 'cuda', share=False)   # (every stream generated: dense or pitched rows)
         assert noise.is_contiguous() == (pad == '0')
         out = uvs.engine.closed_loop(fp, plant, q0, noise, want=want)
         assert out['x'].is_contiguous() == (pad == '0')

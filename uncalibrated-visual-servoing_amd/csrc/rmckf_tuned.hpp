@@ -1292,7 +1292,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
             int it = 1;
             bool more = alive && !fpi.skip && !fpi.poison && (fpi.num > thr2 * fpi.den);  // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
-            if (__any(more)) {
+            if (__builtin_expect(__any(more), 0)) {
                 const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
                 bool skip2 = false;
                 double kk[R][N];
