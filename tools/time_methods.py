@@ -14,19 +14,23 @@ ap.add_argument('--methods', default='GMCKF,KF,IMCCKF,MCKF')
 ap.add_argument('--trials', type=int, default=65536)
 ap.add_argument('--reps', type=int, default=8)
 ap.add_argument('--lanes', type=int, default=0)
+ap.add_argument('--alpha', type=float, default=1.5)
+ap.add_argument('--segments', type=int, default=0, help='segments per trial (bits 8-15 of fp.reserved): 0 = library choice, 1 = whole trials')
 args = ap.parse_args()
 T, dev = args.trials, torch.device('cuda')
 cfg = bench.config2()
 cfg['experiments']['epoch'] = T
 K = len(engine.loop_clock(0.05, 15))
-plan = batch.plan_trials(cfg, cells=[1.5])
-noise = batch.device_noise(cfg, plan, 0, T, K, dev)
+cfg['noise']['noise_params']['alpha'] = args.alpha
+plan = batch.plan_trials(cfg, cells=[args.alpha])
+noise = batch.device_noise(cfg, plan, 0, T, K, dev, share=False)
 q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
 plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
 if args.reps > 1000:
     open('gpurun_out/.probe_started', 'w').write('1')                # tools/power_probe.sh waits for this
 for meth in args.methods.split(','):
     fp = engine.make_params(8, 6, meth, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
+    fp.reserved = args.segments << 8
     ms = []
     for i in range(2 + args.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -63,6 +63,30 @@ constexpr int kFromEven = 0xA0;      // quad_perm [0,0,2,2]: value of the pair's
 constexpr int kFromOdd = 0xF5;       // quad_perm [1,1,3,3]: value of the pair's odd lane
 
 constexpr int kSwapHalf = 0x4E;      // quad_perm [2,3,0,1]: the other pair of the quad
+// Explicit parking of a double in two AGPRs (the "a" constraint keeps the halves in accumulator registers between put and get).  For state that
+// is live THROUGH a register-hungry rare branch: left to itself the allocator keeps such state in VGPRs and runs the branch's own arrays out of
+// AGPRs, one v_accvgpr move per use (measured on the MCKF fixed-point branch: 700 moves per firing against 168 with the covariance blocks parked).
+struct ParkedDouble { int lo, hi; };
+UVS_DEV ParkedDouble agpr_park(double v) {
+    ParkedDouble a;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(__double2loint(v)));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a.hi) : "v"(__double2hiint(v)));
+    return a;
+}
+UVS_DEV double agpr_unpark(const ParkedDouble &a) {
+    int lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
+    return __hiloint2double(hi, lo);
+}
+// DPP row_shr:SH of a double: lane i of a 16-lane row receives lane i - SH (0.0 where that falls out of the row)
+template <int SH>
+UVS_DEV double dpp_row_shr(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SH, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SH, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
 // Sum over the L (1, 2 or 4) lanes of a filter; every lane gets the bit-identical total.
 template <int L>
@@ -117,6 +141,8 @@ struct FpiProbe {
     bool poison = false;                                         // a weight of one of the lane's rows is subnormal: NaN gain, the trial FAILs
     bool unsure = false;                                         // ... or sits so close to the underflow that only the careful pass may decide
     double row_gamma = 0.0, row_a = 0.0, row_nu = 0.0;           // first-pass gain, h.P h and innovation of the row just processed
+    bool known = false;                                          // the caller already holds this row's innovation and weight argument (its pre-pass formed them:
+    double known_nu = 0.0, known_arg = 0.0;                      // the same operations on the same values) -- the row does not form them again
 };
 // exp(x) == 0.0 in fp64 exactly when x < ln(2^-1075) = -745.1332191019412076...  The argument itself carries a few ulp of rounding
 // (1.6e-13 absolute) that differ between this arithmetic and numpy's, so within 1e-11 of the boundary the tuned kernels do not decide
@@ -189,19 +215,17 @@ UVS_DEV void mckf_undo_row(double (&x)[N], double (&pb)[Sym<N>::NP], const doubl
         x[l] = fma(-k1[l], nu, x[l]);
     }
 }
-// One further pass for one row: current iterate xc = x + k nu0 -> new gain row kn (same arithmetic as Rows::update_mckf in
-// rmckf_device.hpp, which the careful / generic kernels run).  Adds this row's share of ||xn - xc||^2 and ||xc||^2; bad: a weight Cy is 0.
+// Lower Cholesky factor of a row's predicted block, packed; the diagonal keeps 1 / L_jj and ljj[] the L_jj themselves.  The predicted block
+// does not change between the passes of a step, so a kernel that keeps a row on one lane factors it once per step (round 4 refactored it every pass).
 template <int N>
-UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::NP], const double (&h)[N], double zi, double neg_half_inv_s2,
-                              const double (&k)[N], double (&kn)[N], double &num, double &den, bool &bad) {
-    double Lc[Sym<N>::NP];                                       // lower Cholesky factor of the predicted block, packed
+UVS_DEV void mckf_factor_row(const double (&pp)[Sym<N>::NP], double (&Lc)[Sym<N>::NP], double (&ljj)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double dsum = pp[Sym<N>::at(j, j)];
 #pragma unroll
         for (int k2 = 0; k2 < j; ++k2) dsum = fma(-Lc[Sym<N>::at(k2, j)], Lc[Sym<N>::at(k2, j)], dsum);
-        double ljj, rl;
-        fast_sqrt_rsqrt(dsum, ljj, rl);
+        double lj, rl;
+        fast_sqrt_rsqrt(dsum, lj, rl);
         Lc[Sym<N>::at(j, j)] = rl;                               // the diagonal keeps 1 / L_jj: only reciprocals of it are ever needed
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
@@ -211,6 +235,15 @@ UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::N
             Lc[Sym<N>::at(j, i)] = v * rl;
         }
     }
+#pragma unroll
+    for (int j = 0; j < N; ++j) ljj[j] = fast_rcp(Lc[Sym<N>::at(j, j)]);       // L_jj back from its reciprocal
+}
+// One further pass for one row: current iterate xc = x + k nu0 -> new gain row kn (same arithmetic as Rows::update_mckf in
+// rmckf_device.hpp, which the careful / generic kernels run).  dd[l] = xn[l] - xc[l] and xcv[l] = xc[l] are this row's terms of
+// ||xn - xc||^2 and ||xc||^2 (the caller sums them in the filter's row order); bad: a weight Cy is 0.
+template <int N>
+UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&Lc)[Sym<N>::NP], const double (&ljj)[N], const double (&h)[N], double zi,
+                              double neg_half_inv_s2, const double (&k)[N], double (&kn)[N], double (&dd)[N], double (&xcv)[N], bool &bad) {
     double nu0 = zi, xc[N], ex[N], t[N], g[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) nu0 = fma(-x[j], h[j], nu0);    // prior innovation (the gain is applied to it, experiment.py:242)
@@ -228,9 +261,6 @@ UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::N
     for (int j = 0; j < N; ++j) ez = fma(-xc[j], h[j], ez);
     const double cy = exp_nonpos((ez * ez) * neg_half_inv_s2);
     bad |= (cy == 0.0);
-    double ljj[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) ljj[j] = fast_rcp(Lc[Sym<N>::at(j, j)]);       // L_jj back from its reciprocal
 #pragma unroll
     for (int j = 0; j < N; ++j) {                                // t = Cx^-1 L^T h
         double v = ljj[j] * h[j];
@@ -251,10 +281,19 @@ UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::N
 #pragma unroll
     for (int l = 0; l < N; ++l) {
         kn[l] = g[l] * gain;
-        const double d = fma(kn[l], nu0, x[l]) - xc[l];
-        num = fma(d, d, num);
-        den = fma(xc[l], xc[l], den);
+        dd[l] = fma(kn[l], nu0, x[l]) - xc[l];
+        xcv[l] = xc[l];
     }
+}
+// Round 4's form (experiment builds with -DUVS_FPI_SPREAD=0): factor, iterate and accumulate in one call, once per pass.
+template <int N>
+UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::NP], const double (&h)[N], double zi, double neg_half_inv_s2,
+                              const double (&k)[N], double (&kn)[N], double &num, double &den, bool &bad) {
+    double Lc[Sym<N>::NP], ljj[N], dd[N], xcv[N];
+    mckf_factor_row<N>(pp, Lc, ljj);
+    mckf_iterate_row<N>(x, Lc, ljj, h, zi, neg_half_inv_s2, k, kn, dd, xcv, bad);
+#pragma unroll
+    for (int l = 0; l < N; ++l) { num = fma(dd[l], dd[l], num); den = fma(xcv[l], xcv[l], den); }
 }
 // Final state of a row after the iteration: x + k nu0 and the Joseph form with a gain row that is no longer gamma (P + Q) h
 // (experiment.py:297): P - k g^T - g k^T + (h.g + 1) k k^T, g = (P + Q) h.
@@ -316,9 +355,14 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
     double g[N];
     double pred = 0.0;
     row_hook<0>(hook);
+    double nu;
+    if (METHOD == UVS_METHOD_MCKF && fpi.known) {
+        nu = fpi.known_nu;
+    } else {
 #pragma unroll
-    for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
-    const double nu = zi - pred;                                 // innovation (experiment.py:274)
+        for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
+        nu = zi - pred;                                          // innovation (experiment.py:274)
+    }
 #ifdef UVS_ABLATE_ROWS
 #pragma unroll
     for (int l = 0; l < N; ++l) g[l] = pb[Sym<N>::at(l, l)] * dq[l];
@@ -351,7 +395,7 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
     } else if constexpr (METHOD == UVS_METHOD_MCKF) {
         // first fixed-point pass: Xc = X, so Cx = I and P_hat = P; gain = 1 / (a + 1 / Cy) (experiment.py:225-242).  The state update
         // and the Joseph form below are then exactly those of the other estimators; kappa of the control law is 1 (:303-308)
-        const double cy = exp_nonpos((nu * nu) * neg_half_inv_s2);
+        const double cy = exp_nonpos(fpi.known ? fpi.known_arg : (nu * nu) * neg_half_inv_s2);
         // skipped correction: X stays, P keeps the prediction (gamma = 0 below).  (A subnormal weight -- fpi.poison -- is not injected here:
         // a select on the gain costs this register-bound kernel 108 B of scratch; the caller FAILs the trial through mckf_poisoned.)
         gamma = fpi.skip ? 0.0 : cy * fast_rcp(fma(a, cy, 1.0));
@@ -669,6 +713,9 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 // scratch inside the step loop); at 1 it takes 270 registers, no scratch, and is faster at every size measured (profiles/r04/shard_times.txt:
 // 8 192 trials 0.97 -> 0.90 ms, 16 384: 1.26 -> 1.00, 32 768: 2.06 -> 1.88).  Four lanes per filter are the LATENCY mapping (UVS_OPT_LATENCY):
 // half the trials per wavefront, 14 % fewer instructions per wavefront-step -- the shards of a strong-scaling series that do not fill the chip.
+#ifndef UVS_FPI_SPREAD                  // experiment builds: 0 = round 4's fixed-point branch (rows iterate on their two owner lanes)
+#define UVS_FPI_SPREAD 1
+#endif
 #ifndef UVS_L4_OCC
 #define UVS_L4_OCC 1
 #endif
@@ -1220,13 +1267,16 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         double kap[R];
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
         FpiProbe fpi;
+        double pre_nu[R], pre_arg[R];                            // MCKF: innovation and weight argument of the lane's rows, from the pre-pass
         if constexpr (METHOD == UVS_METHOD_MCKF) {
             mckf_underflow_prepass<R>(fpi, [&](int r) {
                 double pred = 0.0;
 #pragma unroll
                 for (int j = 0; j < N; ++j) pred = fma(XREG ? xr[XREG ? r : 0][j] : lds_x[XREG ? 0 : r * N + j][lane], dq[j], pred);
                 const double nu = ((z[r] + nz[r]) - f_prev[r]) - pred;
-                return (nu * nu) * neg_half_inv_s2;
+                pre_nu[r] = nu;                                   // the rows below take both from here (same operations, same bits: 9 instructions per row less)
+                pre_arg[r] = (nu * nu) * neg_half_inv_s2;
+                return pre_arg[r];
             });
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;  // one underflowed weight anywhere in the filter skips every row's correction
             fpi.skip |= fp.fpi_epoch_max <= 1;                    // "reached max epoch" after the only pass: correction skipped (:246-250)
@@ -1254,6 +1304,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             } else {
 #pragma unroll
                 for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
+                if constexpr (METHOD == UVS_METHOD_MCKF) { fpi.known = true; fpi.known_nu = pre_nu[r]; fpi.known_arg = pre_arg[r]; }
                 rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
             }
             if constexpr (METHOD == UVS_METHOD_MCKF) { m_gamma[r] = fpi.row_gamma; m_a[r] = fpi.row_a; m_nu[r] = fpi.row_nu; m_z[r] = zi; }
@@ -1292,7 +1343,145 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
             int it = 1;
             bool more = alive && !fpi.skip && !fpi.poison && (fpi.num > thr2 * fpi.den);  // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
+#if UVS_FPI_SPREAD
             if (__builtin_expect(__any(more), 0)) {
+                // ---- the fixed-point branch, spread over the wavefront (round 5).  Round 4 ran it where the state lives: the two lanes of an
+                // iterating filter worked through their four rows each while the other 62 lanes of the wavefront waited (a firing cost ~3 800 issue
+                // slots; with Cauchy noise one wavefront-step in eight fires, 1.2 filters at a time, one extra pass in 98 % of them).  Here every ROW of
+                // an iterating filter gets a lane of its own: a slot of 8 consecutive lanes per filter (up to 8 filters per round, more rounds if more
+                // iterate), lane g of a slot taking global row g.  Row state is fetched where it lives -- X and the parked covariance blocks straight
+                // from the owner's LDS column, the register-resident blocks, the command and the four undo scalars by ds_bpermute -- the row is undone,
+                // factored ONCE (round 4 refactored it every pass), iterated and committed on that lane, and written back the same way.  The only sums
+                // over rows, ||Xn - Xc||^2 and ||Xc||^2, are formed in the owner lanes' order: a chain over local rows 0..R-1 handed from lane g to
+                // lane g + L of the slot (DPP row_shr), then the sum over the L parities -- bit for bit what round 4 computed (tests/test_gpu_digest.py).
+                static_assert(L == 2 && M <= 8, "slots of 8 lanes, rows interleaved over 2 owner lanes");
+                const int g = (int)(lane & 7u), slot = (int)(lane >> 3);
+                const int rr = g >> 1, par = g & 1;                               // owner's local row and parity of global row g
+                unsigned long long todo = __ballot(more) & 0x5555555555555555ull;    // one bit per iterating filter: its even lane
+                while (todo) {                                                    // rounds of up to 8 filters (uniform)
+                    int src_even = -1, my_slot = -1;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; ++sidx) {
+                        if (todo) {                                               // uniform
+                            const int b = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            src_even = (slot == sidx) ? b : src_even;
+                            my_slot = ((int)(lane & ~1u) == b) ? sidx : my_slot;
+                        }
+                    }
+                    const bool act = src_even >= 0 && g < M;                      // this lane works on a row in this round
+                    const int S = (src_even >= 0 ? src_even : (int)(lane & ~1u)) + par;   // owner lane of the row (idle slots look at their own pair: harmless)
+                    const int sa = S << 2;
+                    auto pull = [&](int addr, double v) {
+                        return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+                    };
+                    // which of the owner's R per-row values belongs to this lane's row: all R candidates pulled, one kept
+                    auto pull_row = [&](const double (&v)[R]) {
+                        double got = pull(sa, v[0]);
+#pragma unroll
+                        for (int r = 1; r < R; ++r) { const double c = pull(sa, v[r]); got = (rr == r) ? c : got; }
+                        return got;
+                    };
+                    double *xs = &lds_x[0][0] + (rr < R ? rr : 0) * (N * 64) + S;        // the row's X in its owner's LDS column
+                    double *ps = &lds_p[0][0] + ((rr >= PV && rr < R) ? rr - PV : 0) * (NP * 64) + S;   // ... and its parked covariance block (rows >= PV)
+                    double x[N], pp[NP], h[N], kk[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { x[j] = xs[j * 64]; h[j] = pull(sa, dq[j]); }
+#pragma unroll
+                    for (int e = 0; e < NP; ++e) {
+                        double v = (PL > 0) ? ps[e * 64] : 0.0;
+#pragma unroll
+                        for (int r = 0; r < PV; ++r) { const double c = pull(sa, p[r][e]); v = (rr == r) ? c : v; }
+                        pp[e] = v;
+                    }
+                    const double r_gamma = pull_row(m_gamma), r_a = pull_row(m_a), r_nu = pull_row(m_nu), r_z = pull_row(m_z);
+                    // the register-resident blocks of EVERY lane wait out the round in AGPRs (owners get theirs back from the slot, everyone else from here)
+                    ParkedDouble parked[PV > 0 ? PV : 1][NP];
+#pragma unroll
+                    for (int r = 0; r < PV; ++r)
+#pragma unroll
+                        for (int e = 0; e < NP; ++e) parked[r][e] = agpr_park(p[r][e]);
+                    double Lc[NP], ljj[N];
+                    if (act) {
+                        mckf_undo_row<N>(x, pp, h, r_gamma, r_a, r_nu, kk);       // back to the prior row and the predicted block
+                        mckf_factor_row<N>(pp, Lc, ljj);
+                    }
+                    // (the predicted block is not needed while the row iterates: it waits in AGPRs, like the owners' blocks)
+                    ParkedDouble pp_parked[NP];
+#pragma unroll
+                    for (int e = 0; e < NP; ++e) pp_parked[e] = agpr_park(pp[e]);
+                    bool skip2 = false, more_t = act;
+                    int it_t = 1;
+                    while (__any(more_t)) {
+                        double kn[N], dd[N], xcv[N];
+                        bool bad2 = false;
+#pragma unroll
+                        for (int l = 0; l < N; ++l) { dd[l] = 0.0; xcv[l] = 0.0; kn[l] = 0.0; }
+                        if (more_t) mckf_iterate_row<N>(x, Lc, ljj, h, r_z, neg_half_inv_s2, kk, kn, dd, xcv, bad2);
+                        // ||Xn - Xc||^2 and ||Xc||^2 in the owner lanes' order: local rows 0 .. R-1 of a parity as one chain, passed down the slot
+                        double cn = 0.0, cd = 0.0;
+#pragma unroll
+                        for (int st = 0; st < R; ++st) {
+                            double an = cn, ad = cd;
+#pragma unroll
+                            for (int l = 0; l < N; ++l) { an = fma(dd[l], dd[l], an); ad = fma(xcv[l], xcv[l], ad); }
+                            if (st + 1 < R) { cn = dpp_row_shr<L>(an); cd = dpp_row_shr<L>(ad); }
+                            else { cn = an; cd = ad; }
+                        }
+                        const double num2 = pair_sum<L>(cn), den2 = pair_sum<L>(cd);    // complete on the slot's lanes M - 2, M - 1
+                        const unsigned long long zero_rows = __ballot(bad2 && more_t);
+                        const bool hit_zero = ((zero_rows >> (lane & ~7u)) & 0xffull) != 0;
+                        bool again = false;
+                        if (more_t) {
+                            if (hit_zero) {                                       // inv(Cy) raises: the correction of this step is skipped (:231-236)
+                                skip2 = true;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < N; ++j) kk[j] = kn[j];
+                                ++it_t;
+                                if (it_t == fp.fpi_epoch_max) skip2 = true;       // :246-250
+                                again = !skip2 && (num2 > thr2 * den2) && it_t < fp.fpi_epoch_max;
+                            }
+                        }
+                        // the verdict of the lanes that hold the complete sums, for the whole slot
+                        const unsigned long long verdict = __ballot(again);
+                        more_t = more_t && ((verdict >> ((lane & ~7u) | (unsigned)(M - 1))) & 1ull);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NP; ++e) pp[e] = agpr_unpark(pp_parked[e]);
+                    if (act) {
+                        double unused_chk = 0.0;
+                        if (!skip2) mckf_commit_row<N>(x, pp, h, r_z, kk, unused_chk);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) xs[j * 64] = x[j];
+                        if (rr >= PV) {
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) ps[e * 64] = pp[e];
+                        }
+                        if constexpr (XOUT) {                                     // this step's rows of the X stream: overwrite the optimistic values
+                            long long tf = wave_first + (src_even >> 1);
+                            tf = tf < A.T ? tf : A.T - 1;
+                            double *pxs = A.x_out.at(tf, k, (long long)g * N);
+#pragma unroll
+                            for (int j = 0; j < N; ++j) pxs[j * A.x_out.sc] = x[j];
+                        }
+                    }
+                    // the register-resident blocks return to their owners
+                    const bool is_owner = my_slot >= 0;
+#pragma unroll
+                    for (int r = 0; r < PV; ++r) {
+                        const int ta = ((my_slot < 0 ? 0 : my_slot) * 8 + r * L + sub) << 2;
+#pragma unroll
+                        for (int e = 0; e < NP; ++e) {
+                            const double keep = agpr_unpark(parked[r][e]), c = pull(ta, pp[e]);      // (both unconditionally: straight-line code)
+                            p[r][e] = is_owner ? c : keep;
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+#else
+            if (__any(more)) {                                     // round 4's branch (experiment builds: -DUVS_FPI_SPREAD=0)
                 const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
                 bool skip2 = false;
                 double kk[R][N];
@@ -1371,6 +1560,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
                 asm volatile("" ::: "memory");
             }
+#endif
         }
         if constexpr (METHOD == UVS_METHOD_MCKF && XREG) {       // register-resident variants: first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
