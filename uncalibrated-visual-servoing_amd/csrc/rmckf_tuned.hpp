@@ -921,7 +921,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             auto lds_cell = [&](int i) -> double & {
                 return i < PL * NP ? lds_p[i < PL * NP ? i : 0][lane] : (i < PL * NP + R * N ? lds_x[(i - PL * NP) % (R * N)][lane] : lds_acc[(i - PL * NP - R * N) % (3 * R)][lane]);
             };
-            constexpr int BATCH = NLDS;                                  // (vmcnt lets 63 of them be in flight at once)
+            constexpr int BATCH = 52;                                    // (vmcnt lets 63 of them be in flight at once; 52 = two batches at (8,6), and the size at which the MCKF instantiation spills least)
 #pragma unroll
             for (int b = 0; b < NLDS; b += BATCH) {
                 double tmp[BATCH];
