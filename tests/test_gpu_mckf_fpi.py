@@ -240,6 +240,55 @@ def test_infinite_sample_is_a_skipped_correction_for_mckf(uvs, lanes):
             assert np.all(np.isfinite(X[11, :, 1])) and rel_err(X[11, :, 1], X[10, :, 1]) <= 1e-15    # skipped correction: X unchanged
 
 
+# ---------------------------------------------------------------------------------------------- small batches: four lanes per filter, two-lane bits
+def _same_bits(torch, a, b, K, keys=('x', 'err', 'q')):
+    assert torch.equal(a['status'], b['status']) and torch.equal(a['k_done'], b['k_done'])
+    live = torch.arange(K, device='cuda')[:, None, None] < a['k_done'][None, None, :]
+    for key in keys:
+        assert torch.equal(torch.where(live, a[key], 0.0).view(torch.int64), torch.where(live, b[key], 0.0).view(torch.int64)), key
+    ok = a['status'] == 0
+    assert torch.equal(a['stats'][ok].view(torch.int64), b['stats'][ok].view(torch.int64))
+
+
+@pytest.mark.parametrize('name', FPI)
+def test_small_batch_mapping_keeps_the_two_lane_bits_on_reference_fixtures(uvs, name):
+    """MCKF batches that do not fill the chip run on four lanes per filter (the EMU2 mapping, every fixed-point pass in-kernel) and
+    return the two-lane kernel's bits -- on the reference's own runs that iterate, skip and FAIL."""
+    import ctypes as C
+    import torch
+    g = load_golden(name)
+    k = len(g['t'])
+    plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
+    T = 70
+    q0, nz = _cuda(np.tile(g['q_start'], (T, 1))), _cuda(np.repeat(g['noise_full'][:, :, None], T, axis=2))
+    fp0, fp2 = _fp(uvs, g, 0), _fp(uvs, g, 2)
+    assert uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp0), C.byref(plant), T) == 4 and uvs.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp2), C.byref(plant), T) == 2
+    a = uvs.engine.closed_loop(fp2, plant, q0, nz, want=('x', 'err', 'q', 'f', 'dq'), final_state=True)
+    b = uvs.engine.closed_loop(fp0, plant, q0, nz, want=('x', 'err', 'q', 'f', 'dq'), final_state=True)
+    _same_bits(torch, a, b, a['x'].shape[0], ('x', 'err', 'q', 'f', 'dq'))
+    assert b['status'].cpu().tolist() == [int(g['status'])] * T and b['k_done'].cpu().tolist() == [k] * T
+    if int(g['status']) == 0:
+        for key in ('x_final', 'p_final'):
+            assert torch.equal(a[key].view(torch.int64), b[key].view(torch.int64)), key
+
+
+@pytest.mark.parametrize('thr,cap', [(1e-3, 1000), (1e-4, 3), (0.1, 1000), (1e-2, 1), (1e-6, 40)])
+def test_small_batch_mapping_keeps_the_two_lane_bits_on_mixed_batches(uvs, thr, cap):
+    """150 trials of mixed temper (16 per wavefront on four lanes: several filters of a wavefront iterate at the same step, more than one round of
+    eight slots included at the tight thresholds), iterating up to 40 passes: status, k_done, X / err / q and the statistics bit for bit."""
+    import torch
+    import bench
+    desired = bench.config2()['experiments']['desired_f']
+    T, K = 150, 90
+    q0, noise = _mixed_batch(np.random.default_rng(77), T, K)
+    plant = uvs.SyntheticPlant.ur10(desired).to_struct()
+    outs = []
+    for lanes in (2, 0):
+        fp = uvs.engine.make_params(8, 6, 'MCKF', 10.0, False, 0.05, 15.0, 0.2, desired, True, lanes, K, thr, cap)
+        outs.append(uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q')))
+    _same_bits(torch, outs[0], outs[1], K)
+
+
 # ---------------------------------------------------------------------------------------------- segmented trials (uvs_rmckf_closed_loop_ws_f64)
 def _seg_fp(uvs, base, segments):
     fp = type(base).from_buffer_copy(base)

@@ -141,6 +141,7 @@ struct FpiProbe {
     bool poison = false;                                         // a weight of one of the lane's rows is subnormal: NaN gain, the trial FAILs
     bool unsure = false;                                         // ... or sits so close to the underflow that only the careful pass may decide
     double row_gamma = 0.0, row_a = 0.0, row_nu = 0.0;           // first-pass gain, h.P h and innovation of the row just processed
+    double row_s2 = 0.0, row_gg = 0.0;                           // (gamma nu)^2 and |g|^2 of that row: the terms of num, for kernels that sum them in another lane order (EMU2)
     bool known = false;                                          // the caller already holds this row's innovation and weight argument (its pre-pass formed them:
     double known_nu = 0.0, known_arg = 0.0;                      // the same operations on the same values) -- the row does not form them again
 };
@@ -405,6 +406,8 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         for (int j = 0; j < N; ++j) { gg = fma(g[j], g[j], gg); fpi.den = fma(x[j], x[j], fpi.den); }
         const double s = gamma * nu;
         fpi.num = fma(s * s, gg, fpi.num);                       // ||K (Z - H X)||^2 of this row (0 when skipped: no second pass then)
+        fpi.row_s2 = s * s;
+        fpi.row_gg = gg;
         fpi.row_gamma = gamma;
         fpi.row_a = a;
         fpi.row_nu = nu;
@@ -743,7 +746,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     // keeps only those joints' angles; the camera pose is assembled from the G partial products with DPP broadcasts.
     constexpr bool DH = (PLANT == UVS_PLANT_DH_PINHOLE || PLANT == kPlantDhAxisAligned);
     constexpr bool AXIS = (PLANT == kPlantDhAxisAligned);
-    static_assert(!EMU2 || (L == 4 && M == 8 && N == 6 && METHOD != UVS_METHOD_MCKF), "EMU2: the (8,6) two-lane arithmetic on the four lanes of a quad");
+    static_assert(!EMU2 || (L == 4 && M == 8 && N == 6), "EMU2: the (8,6) two-lane arithmetic on the four lanes of a quad");
     constexpr bool HALVES = (L == 2 || EMU2);                      // the kinematic chain in two halves of three links (else three groups of two)
     static_assert(!AXIS || (HALVES && N == 6), "the axis-aligned chain is written for three links per lane");
     constexpr bool SPLIT = DH && (L == 2 || L == 4) && (N % (HALVES ? 2 : 3) == 0);
@@ -1268,6 +1271,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         double chk = 0.0;                                        // turns NaN as soon as any state entry is non-finite
         FpiProbe fpi;
         double pre_nu[R], pre_arg[R];                            // MCKF: innovation and weight argument of the lane's rows, from the pre-pass
+        double e_s2[R], e_gg[R], den_emu2 = 0.0;                 // MCKF on four lanes with the two-lane bits: terms of the convergence test
         if constexpr (METHOD == UVS_METHOD_MCKF) {
             mckf_underflow_prepass<R>(fpi, [&](int r) {
                 double pred = 0.0;
@@ -1278,6 +1282,19 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 pre_arg[r] = (nu * nu) * neg_half_inv_s2;
                 return pre_arg[r];
             });
+            if constexpr (EMU2) {                                // ||X||^2 of the convergence test in the two-lane kernel's order (its rows add x.x as they go)
+                double d0 = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) d0 = fma(xr[XREG ? r : 0][j], xr[XREG ? r : 0][j], d0);
+                double d1 = dpp_quad<kQuadFromLow>(d0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) d1 = fma(xr[XREG ? r : 0][j], xr[XREG ? r : 0][j], d1);
+                den_emu2 = emu2_finish(d1);
+            }
             fpi.skip = pair_sum<L>(fpi.skip ? 1.0 : 0.0) != 0.0;  // one underflowed weight anywhere in the filter skips every row's correction
             fpi.skip |= fp.fpi_epoch_max <= 1;                    // "reached max epoch" after the only pass: correction skipped (:246-250)
             fpi.poison = pair_sum<L>(fpi.poison ? 1.0 : 0.0) != 0.0;
@@ -1307,7 +1324,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 if constexpr (METHOD == UVS_METHOD_MCKF) { fpi.known = true; fpi.known_nu = pre_nu[r]; fpi.known_arg = pre_arg[r]; }
                 rmckf_row<N, METHOD>(x, pb, dq, zi, neg_half_inv_s2, c_shared, fp.reg, kap[r], chk, fpi);
             }
-            if constexpr (METHOD == UVS_METHOD_MCKF) { m_gamma[r] = fpi.row_gamma; m_a[r] = fpi.row_a; m_nu[r] = fpi.row_nu; m_z[r] = zi; }
+            if constexpr (METHOD == UVS_METHOD_MCKF) { m_gamma[r] = fpi.row_gamma; m_a[r] = fpi.row_a; m_nu[r] = fpi.row_nu; m_z[r] = zi; e_s2[r] = fpi.row_s2; e_gg[r] = fpi.row_gg; }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (XREG) xr[r][j] = x[j];
@@ -1334,12 +1351,21 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
         asm volatile("" ::: "memory");
         UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
-        if constexpr (METHOD == UVS_METHOD_MCKF && !XREG) {
+        if constexpr (METHOD == UVS_METHOD_MCKF && (!XREG || EMU2)) {
             // ---- did the first fixed-point pass settle it (experiment.py:244)?  Rarely not (0.5 % of the steps under Cauchy noise, none
             // for alpha >= 1.3 on the reference's configuration): those lanes take their rows back to the prior state, iterate like
             // Rows::update_mckf and commit the final gain.  The whole wavefront walks through this branch when one of its trials needs it.
-            fpi.num = pair_sum<L>(fpi.num);
-            fpi.den = pair_sum<L>(fpi.den);
+            if constexpr (EMU2) {
+                // the two-lane kernel's chains over its four local rows: the h = 0 lanes start them, the h = 1 lanes finish them (den_emu2 was
+                // formed from the prior X in the pre-pass; the rows left their (gamma nu)^2 and |g|^2 in e_s2 / e_gg)
+                double n1 = dpp_quad<kQuadFromLow>(fma(e_s2[1], e_gg[1], fma(e_s2[0], e_gg[0], 0.0)));
+                n1 = fma(e_s2[1], e_gg[1], fma(e_s2[0], e_gg[0], n1));
+                fpi.num = emu2_finish(n1);
+                fpi.den = den_emu2;
+            } else {
+                fpi.num = pair_sum<L>(fpi.num);
+                fpi.den = pair_sum<L>(fpi.den);
+            }
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
             int it = 1;
             bool more = alive && !fpi.skip && !fpi.poison && (fpi.num > thr2 * fpi.den);  // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
@@ -1354,10 +1380,14 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 // factored ONCE (round 4 refactored it every pass), iterated and committed on that lane, and written back the same way.  The only sums
                 // over rows, ||Xn - Xc||^2 and ||Xc||^2, are formed in the owner lanes' order: a chain over local rows 0..R-1 handed from lane g to
                 // lane g + L of the slot (DPP row_shr), then the sum over the L parities -- bit for bit what round 4 computed (tests/test_gpu_digest.py).
-                static_assert(L == 2 && M <= 8, "slots of 8 lanes, rows interleaved over 2 owner lanes");
+                // EMU2 (four owner lanes per filter, everything in registers): the same branch, with every piece of row state fetched by
+                // ds_bpermute; its rows carry the two-lane kernel's numbering (quad lane p + 2 h holds global rows 4 h + 2 r + p), so the chain below
+                // -- local rows of a PARITY in order, lane g to lane g + 2 -- is the two-lane kernel's in both mappings.
+                static_assert((L == 2 || EMU2) && M <= 8, "slots of 8 lanes; rows interleaved over 2 owner lanes, or the same numbering on a quad");
                 const int g = (int)(lane & 7u), slot = (int)(lane >> 3);
-                const int rr = g >> 1, par = g & 1;                               // owner's local row and parity of global row g
-                unsigned long long todo = __ballot(more) & 0x5555555555555555ull;    // one bit per iterating filter: its even lane
+                const int rr = EMU2 ? ((g >> 1) & 1) : (g >> 1);                  // owner's local row of global row g ...
+                const int own_off = EMU2 ? (g & 1) + 2 * (g >> 2) : (g & 1);      // ... and the owner's position in its lane group
+                unsigned long long todo = __ballot(more) & (EMU2 ? 0x1111111111111111ull : 0x5555555555555555ull);   // one bit per iterating filter: its first lane
                 while (todo) {                                                    // rounds of up to 8 filters (uniform)
                     int src_even = -1, my_slot = -1;
 #pragma unroll
@@ -1366,11 +1396,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                             const int b = __builtin_ctzll(todo);
                             todo &= todo - 1;
                             src_even = (slot == sidx) ? b : src_even;
-                            my_slot = ((int)(lane & ~1u) == b) ? sidx : my_slot;
+                            my_slot = ((int)(lane & ~(unsigned)(L - 1)) == b) ? sidx : my_slot;
                         }
                     }
                     const bool act = src_even >= 0 && g < M;                      // this lane works on a row in this round
-                    const int S = (src_even >= 0 ? src_even : (int)(lane & ~1u)) + par;   // owner lane of the row (idle slots look at their own pair: harmless)
+                    const int S = (src_even >= 0 ? src_even : (int)(lane & ~7u)) + own_off;   // owner lane of the row (idle slots look at lanes of their own: harmless)
                     const int sa = S << 2;
                     auto pull = [&](int addr, double v) {
                         return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
@@ -1382,11 +1412,21 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                         for (int r = 1; r < R; ++r) { const double c = pull(sa, v[r]); got = (rr == r) ? c : got; }
                         return got;
                     };
-                    double *xs = &lds_x[0][0] + (rr < R ? rr : 0) * (N * 64) + S;        // the row's X in its owner's LDS column
-                    double *ps = &lds_p[0][0] + ((rr >= PV && rr < R) ? rr - PV : 0) * (NP * 64) + S;   // ... and its parked covariance block (rows >= PV)
+                    double *xs = &lds_x[0][0] + ((!XREG && rr < R) ? rr : 0) * (N * 64) + (XREG ? 0 : S);   // the row's X in its owner's LDS column
+                    double *ps = &lds_p[0][0] + ((PL > 0 && rr >= PV && rr < R) ? rr - PV : 0) * (NP * 64) + (PL > 0 ? S : 0);   // ... and its parked covariance block (rows >= PV)
                     double x[N], pp[NP], h[N], kk[N];
 #pragma unroll
-                    for (int j = 0; j < N; ++j) { x[j] = xs[j * 64]; h[j] = pull(sa, dq[j]); }
+                    for (int j = 0; j < N; ++j) {
+                        if constexpr (XREG) {                                     // X in the owner's registers: all R candidates pulled, one kept
+                            double v = pull(sa, xr[0][j]);
+#pragma unroll
+                            for (int r = 1; r < R; ++r) { const double c = pull(sa, xr[XREG ? r : 0][j]); v = (rr == r) ? c : v; }
+                            x[j] = v;
+                        } else {
+                            x[j] = xs[j * 64];
+                        }
+                        h[j] = pull(sa, dq[j]);
+                    }
 #pragma unroll
                     for (int e = 0; e < NP; ++e) {
                         double v = (PL > 0) ? ps[e * 64] : 0.0;
@@ -1420,15 +1460,16 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                         if (more_t) mckf_iterate_row<N>(x, Lc, ljj, h, r_z, neg_half_inv_s2, kk, kn, dd, xcv, bad2);
                         // ||Xn - Xc||^2 and ||Xc||^2 in the owner lanes' order: local rows 0 .. R-1 of a parity as one chain, passed down the slot
                         double cn = 0.0, cd = 0.0;
+                        constexpr int CH = M / 2;                                 // local rows of a parity in the two-lane numbering
 #pragma unroll
-                        for (int st = 0; st < R; ++st) {
+                        for (int st = 0; st < CH; ++st) {
                             double an = cn, ad = cd;
 #pragma unroll
                             for (int l = 0; l < N; ++l) { an = fma(dd[l], dd[l], an); ad = fma(xcv[l], xcv[l], ad); }
-                            if (st + 1 < R) { cn = dpp_row_shr<L>(an); cd = dpp_row_shr<L>(ad); }
+                            if (st + 1 < CH) { cn = dpp_row_shr<2>(an); cd = dpp_row_shr<2>(ad); }
                             else { cn = an; cd = ad; }
                         }
-                        const double num2 = pair_sum<L>(cn), den2 = pair_sum<L>(cd);    // complete on the slot's lanes M - 2, M - 1
+                        const double num2 = pair_sum<2>(cn), den2 = pair_sum<2>(cd);    // complete on the slot's lanes M - 2, M - 1
                         const unsigned long long zero_rows = __ballot(bad2 && more_t);
                         const bool hit_zero = ((zero_rows >> (lane & ~7u)) & 0xffull) != 0;
                         bool again = false;
@@ -1452,14 +1493,16 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     if (act) {
                         double unused_chk = 0.0;
                         if (!skip2) mckf_commit_row<N>(x, pp, h, r_z, kk, unused_chk);
+                        if constexpr (!XREG) {
 #pragma unroll
-                        for (int j = 0; j < N; ++j) xs[j * 64] = x[j];
-                        if (rr >= PV) {
+                            for (int j = 0; j < N; ++j) xs[j * 64] = x[j];
+                        }
+                        if (PL > 0 && rr >= PV) {
 #pragma unroll
                             for (int e = 0; e < NP; ++e) ps[e * 64] = pp[e];
                         }
                         if constexpr (XOUT) {                                     // this step's rows of the X stream: overwrite the optimistic values
-                            long long tf = wave_first + (src_even >> 1);
+                            long long tf = wave_first + src_even / L;
                             tf = tf < A.T ? tf : A.T - 1;
                             double *pxs = A.x_out.at(tf, k, (long long)g * N);
 #pragma unroll
@@ -1468,9 +1511,17 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     }
                     // the register-resident blocks return to their owners
                     const bool is_owner = my_slot >= 0;
+                    if constexpr (XREG) {                                         // ... and so does a register-resident X
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int ta = ((my_slot < 0 ? 0 : my_slot) * 8 + 4 * (sub >> 1) + 2 * r + (sub & 1)) << 2;
+#pragma unroll
+                            for (int j = 0; j < N; ++j) { const double c = pull(ta, x[j]); xr[XREG ? r : 0][j] = is_owner ? c : xr[XREG ? r : 0][j]; }
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < PV; ++r) {
-                        const int ta = ((my_slot < 0 ? 0 : my_slot) * 8 + r * L + sub) << 2;
+                        const int ta = ((my_slot < 0 ? 0 : my_slot) * 8 + (EMU2 ? 4 * (sub >> 1) + 2 * r + (sub & 1) : r * L + sub)) << 2;
 #pragma unroll
                         for (int e = 0; e < NP; ++e) {
                             const double keep = agpr_unpark(parked[r][e]), c = pull(ta, pp[e]);      // (both unconditionally: straight-line code)
@@ -1562,7 +1613,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             }
 #endif
         }
-        if constexpr (METHOD == UVS_METHOD_MCKF && XREG) {       // register-resident variants: first pass only, the rest to the careful pass
+        if constexpr (METHOD == UVS_METHOD_MCKF && XREG && !EMU2) {   // plain register-resident variants (L = 1, 4): first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
             fpi.den = pair_sum<L>(fpi.den);
             flagged |= alive && fpi_needs_more(fpi, fp);

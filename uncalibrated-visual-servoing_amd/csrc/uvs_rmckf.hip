@@ -65,14 +65,16 @@ int check_params(const uvs_filter_params *fp, int64_t T, int *lanes) {
 // Four lanes per filter for a closed-loop batch of the (8,6) shape that four-lane wavefronts still run in one round (1024 SIMDs, one wavefront
 // each, 16 trials per wavefront): half the trials per wavefront, a shorter step, 20-28 % less time per launch.  By default
 // -- lanes_per_filter == 0, KF / IMCC-KF / RMCKF on the DH plant -- the EMU2 kernels, which reproduce the two-lane arithmetic bit for bit, so
-// the choice is invisible in the results; with UVS_OPT_LATENCY the plain four-lane kernels (3-7 % faster still, last-bit differences).  MCKF has
-// no four-lane tuned kernel and keeps two lanes.  Returns 0 = no change, 4 = plain four lanes, -4 = four lanes with the two-lane bits.
+// the choice is invisible in the results; with UVS_OPT_LATENCY the plain four-lane kernels (3-7 % faster still, last-bit differences).  MCKF
+// (round 5) has the EMU2 kernel too -- every fixed-point pass in-kernel -- but no plain four-lane one.  Returns 0 = no change, 4 = plain four lanes,
+// -4 = four lanes with the two-lane bits.
 int small_batch_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
-    if (fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || fp->method == UVS_METHOD_MCKF || (T * 4 + 63) / 64 > 1024) return 0;
+    if (fp->lanes_per_filter != 0 || fp->m != 8 || fp->n != 6 || (T * 4 + 63) / 64 > 1024) return 0;
+    if (((fp->reserved >> 8) & 0xff) > 1) return 0;                   // a forced segment count (testing / measurements) asks for the segmented two-lane kernel
     // (eight lanes per filter -- one row per lane on the wide kernel's DH instantiation, lanes_per_filter = 8 -- were built and measured for this
     // role: 8 192 trials 0.92 ms against 0.88 ms on four lanes -- the plant replicated on eight lanes gives back what one row per lane saves
     // (1 075 against 1 109 VALU instructions per wavefront-step): DESIGN.md section 6)
-    if (fp->reserved & UVS_OPT_LATENCY) return 4;
+    if (fp->reserved & UVS_OPT_LATENCY) return fp->method == UVS_METHOD_MCKF ? 0 : 4;   // (the plain four-lane kernels run only MCKF's first pass: no latency mapping for it)
 #ifdef UVS_HAVE_EMU2
     if (plant->kind == UVS_PLANT_DH_PINHOLE && !(fp->reserved & UVS_OPT_STRICT_PINV)) return -4;
 #endif
