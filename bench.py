@@ -506,6 +506,39 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     return out
 
 
+def compact_line(line):
+    """The one JSON line the driver stores has to stay small (round 4's 14 KB line was cut in the driver's record): prose and derivable fields
+    leave it -- every `note` and the kernel / stream descriptions live in README.md "Reading the bench line" -- and nested numbers keep six
+    significant digits.  Contract keys (top level, `config.workload`, `roofline`'s own fields, `cpu_baseline`) are untouched;
+    UVS_BENCH_FULL_JSON=<path> writes the unabridged object."""
+    prose = ('note', 'binds', 'kernel', 'streams', 'inputs', 'source', 'launches_timed', 'noise_gen_workers', 'latency_option', 'h2d_inclusive_updates_per_s',
+             'launches_while_sampling', 'trials_rank0', 'trials_per_gpu')
+    derivable = ('updates_per_s', 'updates_per_launch', 'algorithmic_bytes_per_update', 'unit', 'peak', 'wall_ms', 'updates_total', 'wave_instr_per_s',
+                 'fp64_peak_flops', 'per_process_updates_per_s', 'min_kernel_ms', 'layout', 'cells', 'trials_per_cell')
+
+    def walk(o, path):
+        depth = len(path)
+        if isinstance(o, dict):
+            out = {}
+            for k, v in o.items():
+                top = path[0] if path else k
+                if depth > 0 and top != 'cpu_baseline' and (k in prose or k.endswith('_note')) and not (top == 'roofline' and depth == 1 and k == 'kernel'):
+                    continue
+                if k == 'workload' and path != ('config',):
+                    continue
+                if (depth > 1 or (depth == 1 and top not in ('roofline', 'config', 'cpu_baseline'))) and k in derivable and top != 'cpu_baseline':
+                    continue
+                out[k] = walk(v, path + (k,))
+            return out
+        if isinstance(o, list):
+            return [walk(v, path + ('[]',)) for v in o]
+        if isinstance(o, float) and depth > 1 and not (path[0] == 'roofline' and depth == 2):
+            return float(f'{o:.6g}')
+        return o
+
+    return walk(line, ())
+
+
 PROFILER_ENV_PREFIXES = ('ROCP', 'ROCTRACER', 'HSA_TOOLS', 'ROCTX')
 
 
@@ -933,6 +966,28 @@ def main():
                     entry[mode] = {'kernel_ms': float(np.mean(ms)), 'lanes_per_filter': int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp_m), C.byref(plant), Ts)),
                                    'implied_speedup': avg_ms / float(np.mean(ms))}
                 shard_model['shards'][f'N={n_ranks}'] = entry
+            # the reference's shipped estimator (config.json: MCKF) on the same shards: two lanes per filter (round 4's only mapping) against the library's
+            # choice (round 5: four lanes with the two-lane bits up to 16 384 trials, every fixed-point pass in-kernel)
+            shard_model['mckf'] = {}
+            for n_ranks in (4, 8):
+                Ts = T // n_ranks
+                entry = {'trials': Ts}
+                for mode, lanes_m in (('two_lanes', 2), ('default_mapping', 0)):
+                    fp_m = engine.make_params(M, N, 'MCKF', fp.kernel_bw, bool(fp.annealing), fp.dt, fp.dt * fp.k_max, fp.gain, list(fp.desired)[:M], bool(fp.initial_guess), lanes_m)
+                    ms = []
+                    for i in range(2 + 5):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        rc = engine.launch_closed_loop(fp_m, plant, Ts, flat(q0[:Ts]), engine.stream_view(noise[:, :, :Ts], 'kct'), NV, engine.stream_view(bufs['x'][:, :, :Ts], 'kct'),
+                                                       engine.stream_view(bufs['err'][:, :, :Ts], 'kct'), engine.stream_view(bufs['q'][:, :, :Ts], 'kct'), NV, NV, stats.data_ptr(),
+                                                       status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev)
+                        uvs_amd._lib.check(rc)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if i >= 2:
+                            ms.append(e0.elapsed_time(e1))
+                    entry[mode] = {'kernel_ms': float(np.mean(ms)), 'lanes_per_filter': int(uvs_amd.lib().uvs_rmckf_closed_loop_lanes(C.byref(fp_m), C.byref(plant), Ts))}
+                shard_model['mckf'][f'N={n_ranks}'] = entry
         power = None
         if world == 1 and not args.no_power:                       # after the short side measurements above (seconds of sustained load change what follows)
             power = power_under_load(torch, launch, torch.cuda.current_device())
@@ -953,9 +1008,11 @@ def main():
                 side['config3_hold'] = side_config(3, torch, uvs_amd, engine, batch, dev, hold=True)
                 side['config5'] = side_config(5, torch, uvs_amd, engine, batch, dev)
         series = {'strong': f'strong scaling: {trials_total} trials in total, sharded contiguously over {world} rank(s)' +
-                            (" -- north_star's series (a 65 536-trial batch at 1, 2, 4 and 8 MI355X)" if args.config == 2 and trials_total == TRIALS_PER_GPU else '') +
+                            (" -- north_star's series (a 65 536-trial batch at 1, 2, 4 and 8 MI355X); a trial is a 299-step serial chain, so by kernel time this "
+                             "series tops out at <= 3.3x at N = 8 (8 192-trial shard 0.93 ms vs 3.0 ms); the weak series / config 4 is the scaling series" if args.config == 2 and trials_total == TRIALS_PER_GPU else '') +
                             (' -- BASELINE config 4' if args.config == 4 else ''),
-                  'weak': f'weak scaling: {size} trials on every one of {world} rank(s), global trial numbering'}[scaling]
+                  'weak': f'weak scaling: {size} trials on every one of {world} rank(s), global trial numbering (the scaling series; the strong 65 536-trial series of north_star is '
+                          'bounded at <= 3.3x at N = 8 by kernel time -- a trial is a 299-step serial chain -- and is reported as multi_gpu.strong_series)'}[scaling]
         line = {
             'metric': 'RMCKF updates/s (4-feat, 6-DoF) over MC batch', 'value': value, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -982,7 +1039,11 @@ def main():
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},
         }
-        print(json.dumps(line))
+        full_path = os.environ.get('UVS_BENCH_FULL_JSON')
+        if full_path:                                              # the unabridged object, notes included (profiles/rNN/bench_full.json is written this way)
+            with open(full_path, 'w') as fh:
+                json.dump(line, fh, indent=1)
+        print(json.dumps(compact_line(line), separators=(',', ':')))
     if dist_on:
         td.destroy_process_group()
 
