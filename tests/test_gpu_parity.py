@@ -845,6 +845,35 @@ def test_pitched_streams_give_the_same_bits(uvs, method, monkeypatch):
         assert np.array_equal(res['0'][k], res['37'][k], equal_nan=True), k
 
 
+@pytest.mark.parametrize('T', [333, 4096])
+@pytest.mark.parametrize('method', ['GMCKF', 'KF', 'IMCCKF', 'MCKF'])
+def test_record_layout_gives_the_same_bits(uvs, method, T):
+    """with per-trial records for the streams ([step][trial][component], layout 'ktc') the (8,6) two-lane kernels of KF / IMCC-KF
+    write X as whole 128-byte lines out of LDS (the XREC instantiation); RMCKF (measured: slower that way) and MCKF keep their strided stores.  Every stream, the statistics and
+    the status bit for bit as with the trial-fastest layout -- ragged last wavefront included (T = 333: 13 of its 32 records exist)."""
+    import torch
+    import bench
+    cfg = bench.config2()
+    cfg['experiments']['epoch'] = T
+    plan = uvs.batch.plan_trials(cfg, cells=[1.5])
+    K = 45
+    fp = uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 2, steps=K, fpi_threshold=0.1, fpi_epoch_max=50)
+    plant = uvs.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    q0 = _cuda(plan.q_start)
+    noise = uvs.batch.device_noise(cfg, plan, 0, T, K, 'cuda', share=False)                # [K][8][T]
+    want = ('x', 'err', 'q', 'f', 'dq')
+    a = uvs.engine.closed_loop(fp, plant, q0, noise, want=want, layout='kct')
+    b = uvs.engine.closed_loop(fp, plant, q0, noise.permute(0, 2, 1).contiguous(), want=want, layout='ktc')
+    assert b['x'].shape == (K, T, 48) and b['x'].is_contiguous()
+    assert torch.equal(a['status'], b['status']) and torch.equal(a['k_done'], b['k_done']) and torch.equal(a['stats'].view(torch.int64), b['stats'].view(torch.int64))
+    for key in want:
+        ta, tb = uvs.engine.as_tkc(a[key], 'kct'), uvs.engine.as_tkc(b[key], 'ktc')
+        assert torch.equal(ta.contiguous().view(torch.int64), tb.contiguous().view(torch.int64)), key
+    c = uvs.engine.closed_loop(fp, plant, q0, noise, want=want, layout='kct', x_layout='ktc')      # records for X alone, narrow streams trial-fastest
+    assert c['x'].shape == (K, T, 48) and c['err'].shape == (K, 8, T) and torch.equal(c['x'].view(torch.int64), b['x'].view(torch.int64))
+    assert torch.equal(c['err'].view(torch.int64), a['err'].view(torch.int64)) and torch.equal(c['stats'].view(torch.int64), a['stats'].view(torch.int64))
+
+
 def test_alloc_stream_row_pitch_knob(uvs, monkeypatch):
     """UVS_ROW_PAD pitches the rows of trial-fastest streams; the caller sees the [K][comp][T] view either way."""
     eng = uvs.engine

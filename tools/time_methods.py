@@ -15,6 +15,7 @@ ap.add_argument('--trials', type=int, default=65536)
 ap.add_argument('--reps', type=int, default=8)
 ap.add_argument('--lanes', type=int, default=0)
 ap.add_argument('--alpha', type=float, default=1.5)
+ap.add_argument('--x-layout', default=None, help="layout of the X stream alone ('ktc' = per-trial records)")
 ap.add_argument('--segments', type=int, default=0, help='segments per trial (bits 8-15 of fp.reserved): 0 = library choice, 1 = whole trials')
 args = ap.parse_args()
 T, dev = args.trials, torch.device('cuda')
@@ -35,9 +36,9 @@ for meth in args.methods.split(','):
     for i in range(2 + args.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+        out = engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'), x_layout=args.x_layout)
         e1.record(); torch.cuda.synchronize()
         if i >= 2:
             ms.append(e0.elapsed_time(e1))
     upd = int(out['k_done'].sum())
-    print(f'{meth:7s} lanes={args.lanes}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f})  {upd / np.mean(ms) / 1e6:.2f} G updates/s  {upd * 560 / np.mean(ms) / 1e9:.2f} TB/s  failed {int((out["status"] != 0).sum())}')
+    print(f'{meth:7s} lanes={args.lanes} x_layout={args.x_layout}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f})  {upd / np.mean(ms) / 1e6:.2f} G updates/s  {upd * 560 / np.mean(ms) / 1e9:.2f} TB/s  failed {int((out["status"] != 0).sum())}')

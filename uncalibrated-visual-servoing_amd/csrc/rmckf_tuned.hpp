@@ -728,10 +728,15 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 // SEGMENTED: the instantiation can run a trial chunk as several work items (see SEG below).  Always for MCKF, whose wavefronts differ in length;
 // for RMCKF a second instantiation that the launcher picks only when a launch is not a whole number of rounds of wavefronts (the code costs the
 // headline kernel 4 registers and 0.4 %, so the headline launch keeps the instantiation without it).
-template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF)>
+// XREC (round 5): the X stream as per-trial RECORDS -- [step][trial][m n], comp_stride 1 -- written straight out of the LDS-resident X after the
+// rows of a step: 12 stores of 16 bytes per lane, each covering eight whole 128-byte lines, instead of 24 stores of 8 bytes per lane scattered
+// over 48 rows of the trial-fastest layout.  KF / IMCC-KF are bound by the CU's store path; the launcher picks this
+// instantiation when the caller's x_out view has that shape.
+template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false>
 __global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
+    static_assert(!XREC || (XOUT && L == 2 && !EMU2 && M == 8 && N == 6 && METHOD != UVS_METHOD_MCKF), "record stores: the (8,6) two-lane kernels with X in LDS (MCKF rewrites rows of a step)");
 #ifdef UVS_L4_XLDS
     constexpr bool XREG = false;
 #else
@@ -1008,7 +1013,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     if constexpr (SEG) {
         if (k_begin > 0) {                                       // a later segment: every stream cursor to its first step
             if (on_noise) pn += (long long)k_begin * A.noise.sk;
-            if constexpr (XOUT) px += (long long)k_begin * A.x_out.sk;
+            if constexpr (XOUT && !XREC) px += (long long)k_begin * A.x_out.sk;
             if (on_err) pe += (long long)k_begin * A.err_out.sk;
             if (on_f) pf += (long long)k_begin * A.f_out.sk;
             if (on_q) pq += (long long)k_begin * A.q_out.sk;
@@ -1041,8 +1046,37 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id_));
         fair_slot = hw_id_ & 1u;                                 // WAVE_ID bit 0
     }
+    auto store_records = [&](int k) {                            // XREC: the records of step k, straight out of the LDS-resident X
+#ifndef UVS_XREC_DIRECT
+        if constexpr (XREC) {
+            // The wavefront's 32 records of this step are 12 KB of contiguous memory.  Store a = 0..3, b = 0..2: lane (tg, pp) = (lane / 8, lane % 8)
+            // writes pair 8 b + pp (two consecutive components, 16 bytes) of trial 8 a + tg -- eight trials x 128 contiguous bytes per instruction.
+            // The pair sits in one row of X (N is even): LDS cell [r N + j][2 trial + s] and the one 64 doubles further.
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const int tg = (int)(lane >> 3), pp8 = (int)(lane & 7u);
+            double *rec = A.x_out.p + (long long)k * A.x_out.sk + wave_first * (long long)(M * N) + tg * (M * N);
+            const double *xl = &lds_x[0][0] + 2 * tg;
+#pragma unroll
+            for (int b = 0; b < (M * N / 2) / 8; ++b) {
+                const int cp = 8 * b + pp8;                              // pair within the record
+                const int row = cp / (N / 2), jj = 2 * (cp % (N / 2));   // (lane constants: hoisted out of the step loop by the compiler)
+                const int cell = ((row >> 1) * N + jj) * 64 + (row & 1);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    v2d v;
+                    v.x = xl[cell + 16 * a];
+                    v.y = xl[cell + 64 + 16 * a];
+                    if (wave_first + 8 * a + tg < A.T) *reinterpret_cast<v2d *>(rec + (long long)(8 * a) * (M * N) + 2 * cp) = v;
+                }
+            }
+        }
+#endif
+    };
     for (int k = k_begin; k < k_end; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
+        // (XREC) the records of the PREVIOUS step leave now: their LDS reads and stores have the whole plant phase to drain under -- issued in one
+        // burst behind the rows they stalled the wavefront at the full store queue (measured: RMCKF + 7 %)
+        if constexpr (XREC) { if (k > k_begin) store_records(k - 1); }
         UVS_STAMP(5);
         if constexpr (FAIR) {
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();
@@ -1330,7 +1364,15 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 if constexpr (XREG) xr[r][j] = x[j];
                 else lds_x[r * N + j][lane] = x[j];
             }
-            if constexpr (XOUT) {
+#ifdef UVS_XREC_DIRECT                  // experiment: records written from the rows' own registers, 16 bytes per lane and store (no LDS transposition)
+            if constexpr (XREC) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                double *rr_ = A.x_out.p + (long long)k * A.x_out.sk + trial * (long long)(M * N) + (r * RS + rb) * N;
+#pragma unroll
+                for (int j = 0; j < N; j += 2) { v2d v; v.x = x[j]; v.y = x[j + 1]; *reinterpret_cast<v2d *>(rr_ + j) = v; }
+            }
+#endif
+            if constexpr (XOUT && !XREC) {
 #ifdef UVS_ABLATE_STORES
                 if (k == K - 1)
 #endif
@@ -1347,7 +1389,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
             }
         }
-        if constexpr (XOUT) px += UVS_SK(A.x_out.sk);
+        if constexpr (XOUT && !XREC) px += UVS_SK(A.x_out.sk);
         // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
         asm volatile("" ::: "memory");
         UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
@@ -1735,6 +1777,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int u = 0; u < JG; ++u) q[u] = fma(dq_own[u], fp.dt, q[u]);       // new_q = q + dq t_s (experiment.py:320)
         t += fp.dt;
     }
+    if constexpr (XREC) { if (k_end > k_begin) store_records(k_end - 1); }   // the last step's records (after a wavefront-wide FAIL: rows past every k_done, unspecified)
 #ifdef UVS_STAMPS
     {
         unsigned long long rt_last;

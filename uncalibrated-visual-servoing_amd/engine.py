@@ -118,15 +118,18 @@ def launch_closed_loop(fp, plant_struct, T, *args, device=None):
     return _lib.lib().uvs_rmckf_closed_loop_ws_f64(C.byref(fp), C.byref(plant_struct), T, *args, ws, ws_bytes, _stream())
 
 
-def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False):
+def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False, x_layout=None):
     """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
-    ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``)."""
+    ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``).
+    ``x_layout``: another layout for the X stream alone -- 'ktc' (per-trial records) is the fast store path of the (8,6) KF / IMCC-KF / RMCKF
+    kernels, whatever the layout of the narrow streams (which are coalesced as trial-fastest rows)."""
+    x_layout = x_layout or layout
     torch = _torch()
     T, K, m, n = q_start.shape[0], fp.steps, fp.m, fp.n
     dev = q_start.device
     out = {}
     for key, comp in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)):
-        out[key] = alloc_stream(T, K, comp, layout, dev) if key in want else None      # rows at and after k_done are unspecified
+        out[key] = alloc_stream(T, K, comp, x_layout if key == 'x' else layout, dev) if key in want else None      # rows at and after k_done are unspecified
     out['stats'] = torch.zeros((T, 3), dtype=torch.float64, device=dev)
     out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
     out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -138,7 +141,7 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     start.record()                                                                                     # allocations above are not kernel time
     rc = _lib.lib().uvs_rmckf_closed_loop_ws_f64(
         C.byref(fp), C.byref(plant_struct), T, flat(q_start), stream_view(noise, layout), flat(x0),
-        stream_view(out['x'], layout), stream_view(out['err'], layout), stream_view(out['q'], layout),
+        stream_view(out['x'], x_layout), stream_view(out['err'], layout), stream_view(out['q'], layout),
         stream_view(out['f'], layout), stream_view(out['dq'], layout),
         out['stats'].data_ptr(), out['status'].data_ptr(), out['k_done'].data_ptr(),
         flat(out['x_final']), flat(out['p_final']), ws, ws_bytes, _stream())
