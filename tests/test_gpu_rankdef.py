@@ -36,10 +36,11 @@ def _fp(uvs, g, lanes=0, steps=None, strict=False):
     return fp
 
 
-# The one fixture no magnitude of the triangular factor gives away (unit diagonal, every off-diagonal -1000: condition 3e18).  The fast
-# kernels return the plain least-squares command there -- pinned below so that the boundary is a tested fact, not a comment -- and
-# UVS_OPT_STRICT_PINV returns numpy's.
-BLIND = 'rankdef_gmckf_kahan_c1000'
+# The one fixture no magnitude of the triangular factor gives away (unit diagonal, every off-diagonal -1000: condition 3e18).  Until round 4
+# the fast kernels returned the plain least-squares command there; since round 5 every solve also watches the GROWTH of its solution
+# (max|sol| max|R| / max|Q^T y| >= 2^34, Spread::grows -- 2.4e15 or more on every step of this fixture, at most 4e2 on the healthy ones,
+# tests/growth_watch_study.py), the trial is marked and the careful pass returns numpy's command in the default mode too.
+KAHAN = 'rankdef_gmckf_kahan_c1000'
 
 
 @pytest.mark.parametrize('lanes', LANES_86)
@@ -56,9 +57,6 @@ def test_replay_matches_reference_on_rank_deficient_jacobians(uvs, name, lanes):
     assert np.array_equal(cmd[:, :, 0], cmd[:, :, 2], equal_nan=True)
     assert rel_err(X[g['X_steps'], :, 0][:h], g['X'][:h]) <= 1e-10
     assert set(out['status'].cpu().numpy().tolist()) == {0} and int(out['k_done'][0]) == K
-    if name == BLIND and lanes != 0:                                                 # the documented blind spot of the QR solvers: NOT numpy's command
-        assert rel_err(cmd[:h - 1, :, 0], g['dq_prev'][1:h]) > 1.0                   # (lanes 0 replays through the control wavefronts: normal equations,
-        return                                                                       #  gate 2^20 on pivots AND column norms -- those do mark this Jacobian)
     assert rel_err(cmd[:h - 1, :, 0], g['dq_prev'][1:h]) <= RANKDEF_CMD_TOL.get(name, 1e-8)     # pinv's truncated minimum-norm command
 
 
@@ -80,20 +78,20 @@ def test_strict_pinv_replay_matches_reference_everywhere(uvs, name, lanes):
     assert set(out['status'].cpu().numpy().tolist()) == {0} and int(out['k_done'][0]) == K
 
 
-def test_strict_pinv_closed_loop_on_the_blind_fixture(uvs):
-    """Closed loop from the Kahan-like X0: with the option the trajectory is the reference's; without it the command is another one from
-    the first step on (the reference's truncated command is ~1e-5 rad/s, the plain least-squares one is not)."""
-    g = load_golden(BLIND)
+@pytest.mark.parametrize('lanes,strict', [(0, False), (2, False), (4, False), (1, False), (-2, False), (0, True)])
+def test_closed_loop_on_the_kahan_fixture(uvs, lanes, strict):
+    """Closed loop from the Kahan-like X0: the reference's trajectory -- its truncated command is ~1e-5 rad/s, the plain
+    least-squares one is hundreds of times larger -- in the DEFAULT mode on every lane mapping (the growth watch marks the trial at its first
+    solve), and with UVS_OPT_STRICT_PINV as before."""
+    g = load_golden(KAHAN)
     K = len(g['t'])
     plant = uvs.SyntheticPlant.ur10(scene_desired(g)).to_struct()
     args = (plant, _cuda(np.tile(g['q_start'], (3, 1))), _cuda(np.repeat(g['noise'][:, :, None], 3, axis=2)), _cuda(np.tile(g['X'][0], (3, 1))))
-    strict = uvs.engine.closed_loop(_fp(uvs, g, 0, strict=True), *args, want=('x', 'err', 'q', 'dq'))
-    assert strict['status'].cpu().tolist() == [0] * 3 and strict['k_done'].cpu().tolist() == [K] * 3
-    err, q, X, dq = (strict[k].cpu().numpy()[:, :, 1] for k in ('err', 'q', 'x', 'dq'))
+    out = uvs.engine.closed_loop(_fp(uvs, g, lanes, strict=strict), *args, want=('x', 'err', 'q', 'dq'))
+    assert out['status'].cpu().tolist() == [0] * 3 and out['k_done'].cpu().tolist() == [K] * 3
+    err, q, X, dq = (out[k].cpu().numpy()[:, :, 1] for k in ('err', 'q', 'x', 'dq'))
     assert rel_err(err, g['err']) <= 1e-7 and rel_err(q, g['q']) <= 1e-7 and rel_err(X[g['X_steps']], g['X']) <= 1e-7
     assert rel_err(dq[:K - 1], g['dq_prev'][1:]) <= 1e-6
-    fast = uvs.engine.closed_loop(_fp(uvs, g, 0), *args, want=('dq',))
-    assert np.abs(fast['dq'].cpu().numpy()[0, :, 1]).max() > 100 * np.abs(g['dq_prev'][1]).max()
 
 
 def test_strict_pinv_agrees_with_the_fast_path_on_healthy_trials(uvs):
@@ -111,9 +109,9 @@ def test_strict_pinv_agrees_with_the_fast_path_on_healthy_trials(uvs):
     assert rel_err(outs[1]['err'].cpu().numpy(), outs[0]['err'].cpu().numpy()) <= 1e-9
 
 
-# closed loop: not the fixtures whose reference command is itself only defined to 1e-3 (the loop amplifies that), not the blind one (strict test above)
+# closed loop: not the fixtures whose reference command is itself only defined to 1e-3 (the loop amplifies that), not the Kahan-like one (its own test above)
 @pytest.mark.parametrize('lanes', (0, -2, 4))
-@pytest.mark.parametrize('name', [n for n in RANKDEF if n not in HORIZON and n not in RANKDEF_CMD_TOL and n != BLIND])
+@pytest.mark.parametrize('name', [n for n in RANKDEF if n not in HORIZON and n not in RANKDEF_CMD_TOL and n != KAHAN])
 def test_closed_loop_matches_reference_on_rank_deficient_jacobians(uvs, name, lanes):
     g = load_golden(name)
     K = len(g['t'])

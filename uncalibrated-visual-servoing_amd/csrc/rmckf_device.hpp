@@ -441,6 +441,7 @@ struct Rows {
 constexpr int UVS_STATUS_SUSPECT = 2;            // internal: never visible after an entry point returns
 constexpr unsigned kSuspectSpread = 68u << 20;   // exponent-field distance (high dword of a double) of R_cc^2: |R_cc| spread 2^34 ~ 1.7e10
 constexpr double kPinvRcond = 1e-15;             // numpy.linalg.pinv default (rcond=1e-15)
+constexpr unsigned kGrowthGate = (0x3ff00000u + kSuspectSpread) / 2;   // log2(max|sol|) + log2(max|R|) - log2(max|Q^T y|) >= 34, see Spread::grows
 
 // Running exponent range of the non-negative doubles R_cc^2 (their high dwords order like the values; a zero column gives 0).
 struct Spread {
@@ -458,6 +459,19 @@ struct Spread {
         unsigned e2 = h >= 0x20000000u ? 2u * h - 0x3ff00000u : 0u;             // (below 2^-511 the square underflows: no information)
         e2 = e2 > 0x7ff00000u ? 0x7ff00000u : e2;                               // a square beyond the range reads as +inf ("suspect"), never as NaN ("non-finite")
         hi = e2 > hi ? e2 : hi;
+    }
+    // Solution growth (round 5; call after add_largest): max |sol_c| * max |R_ij| / max |(Q^T y)_c| >= 2^34, in the exponent fields like everything
+    // here (hi holds the SQUARE of the largest entry, hence the shift; within a factor 8).  sigma_max / sigma_min is at least this ratio, and
+    // unlike the spread of the factor's entries it also sees a triangle of unremarkable entries whose inverse explodes (Kahan-like: unit
+    // diagonal, off-diagonals -1000, condition 3e18) -- whenever the right-hand side excites the small direction, which is exactly when the
+    // plain least-squares command and numpy's truncated one differ materially.  On the reference fixtures the ratio is <= 4e2 for every healthy
+    // step (49 closed-loop / fixed-point fixtures) and >= 2.4e15 on every step of rankdef_gmckf_kahan_c1000 (tests/growth_watch_study.py).
+    UVS_DEV bool grows(double smax, double cmax) const {
+#ifdef UVS_NO_GROWTH_WATCH              // experiment builds: A/B of the watch's cost (its inputs then fold away)
+        return false;
+#endif
+        const unsigned hs = (unsigned)__double2hiint(smax), hc = (unsigned)__double2hiint(cmax);
+        return hs + (hi >> 1) >= hc + kGrowthGate;                              // (every term below 2^31: no wrap)
     }
     // lo == 0: a column vanished altogether (all of them when hi == 0 too, J = 0, where the plain solve would divide 0 by 0)
     UVS_DEV bool suspect() const { return hi - lo >= kSuspectSpread || lo == 0u; }
@@ -671,7 +685,12 @@ UVS_DEV bool lstsq_tall(double (&a)[M / L][N + 1], int sub, double (&sol)[N]) {
         rhs = group_pick<L>(rhs, sub, owner);
         sol[c] = rhs * diag[c];
     }
-    return suspect;
+    double smax = 0.0, cmax = 0.0;                               // solution growth (Spread::grows): the top N entries of Q^T y against the solution
+#pragma unroll
+    for (int c = 0; c < N; ++c) smax = fmax(smax, fabs(sol[c]));
+#pragma unroll
+    for (int r = 0; r < R; ++r) cmax = fmax(cmax, (sub * R + r < N) ? fabs(a[r][N]) : 0.0);
+    return suspect || spread.grows(smax, group_max<L>(cmax));
 }
 
 // Underdetermined case (M < N, e.g. one feature: 2 x 6): minimum-norm solution through the QR of J^T.

@@ -550,6 +550,17 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
         rhs = pair_from_dyn<L>(rhs, owner);
         sol[c] = rhs * rdiag[c];
     }
+    // solution growth (Spread::grows, round 5): the largest solution entry against the largest of the top N entries of Q^T y
+    double smax = fabs(sol[0]), cmax = 0.0;
+#pragma unroll
+    for (int c = 1; c < N; ++c) smax = fmax(smax, fabs(sol[c]));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r * L < N) cmax = fmax(cmax, ((r + 1) * L <= N || r * L + sub < N) ? fabs(a[r][N]) : 0.0);
+    }
+    if constexpr (L > 1) cmax = fmax(cmax, dpp_quad<kSwapPair>(cmax));
+    if constexpr (L == 4) cmax = fmax(cmax, dpp_quad<kSwapHalf>(cmax));
+    const bool grows = spread.grows(smax, cmax);
     // (a column that vanished exactly -- lo == 0 -- sends NaNs through the remaining columns by itself: that trial is marked for the careful
     // second pass, which probes X entry by entry, and is not FAILed here)
     // NaN (high dword above +inf's 0x7ff00000) proves a non-finite entry.  A norm of exactly +inf does not: a FINITE entry beyond ~1e154
@@ -557,7 +568,7 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     // entry) instead of FAILed here.  An infinite entry in any but the last column turns a later column's norm into NaN (0 * inf in the
     // reflector); in the last column it goes the careful way too and FAILs there, at the same step.
     nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
-    return spread.suspect() || spread.hi == 0x7ff00000u;
+    return spread.suspect() || spread.hi == 0x7ff00000u || grows;
 }
 
 template <int M, int N, int L>
@@ -674,8 +685,15 @@ UVS_DEV bool lstsq_tall_emu2(double (&a)[2][N + 1], int sub, double (&sol)[N], b
         rhs = pair_from_dyn<4>(rhs, owner + 2 * hm);
         sol[c] = rhs * rdiag[c];
     }
+    // solution growth: the two-lane kernel's verdict -- the same maxima (global rows 0 .. N-1 of Q^T y: both rows of the h = 0 lanes, row 0 of the h = 1 lanes)
+    double smax = fabs(sol[0]), cmax = fabs(a[0][N]);
+#pragma unroll
+    for (int c = 1; c < N; ++c) smax = fmax(smax, fabs(sol[c]));
+    cmax = fmax(cmax, high ? 0.0 : fabs(a[1][N]));
+    cmax = fmax(cmax, dpp_quad<kSwapPair>(cmax));
+    cmax = fmax(cmax, dpp_quad<kSwapHalf>(cmax));
     nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
-    return spread.suspect() || spread.hi == 0x7ff00000u;
+    return spread.suspect() || spread.hi == 0x7ff00000u || spread.grows(smax, cmax);
 }
 
 // Internal plant kind (not part of the ABI): UVS_PLANT_DH_PINHOLE whose DH table has, in either half of a six-link chain, alpha = -pi/2 on
