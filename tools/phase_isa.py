@@ -25,36 +25,51 @@ def classify(op):
         if 'add' in op: return 'f64 add'
         return 'f64 other'
     if op.startswith('v_mov') and 'dpp' in op: return 'dpp mov'
+    if op.startswith('v_permlane'): return 'permlane'
     if op.startswith('v_'): return 'valu other'
     return 'other'
 
 
+WIDE_KERNEL = '_ZN3uvs23closed_loop_wide_kernelILi32ELi7ELi8ELi5ELb1ELb1ELi1EEEvNS_10ClosedArgsE'
+# the wide kernel's stamps in loop order: loop edge (7), plant (0), rows (1), record stores (2), Gram + sums (3), Cholesky + refinement (5), logs (6)
+WIDE_PHASES = ['loop edge: integrate q, clock (stamp 7)', 'noise issue + plant + measurement (0)', 'row updates + X into the record buffer (1)', 'record stores (2)',
+               'Gram + rhs + 36 sums over 8 lanes (3)', 'Cholesky + solve + refinement + solve (5)', 'logs + statistics (6)']
+
+
 def main(path):
+    global KERNEL, PHASES
+    if '--wide' in sys.argv:
+        KERNEL, PHASES = WIDE_KERNEL, WIDE_PHASES
+    NST = len(PHASES)
     s = open(path).read()
     a = s.index('\n' + KERNEL + ':')
     body = s[a:s.index('s_endpgm', a)].splitlines()
-    labels = {l.strip()[:-1]: i for i, l in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', l.strip())}
-    best = None                                                    # the step loop: the shortest backward branch whose span holds all six stamps
-    for i, l in enumerate(body):
-        m = re.match(r'\s*s_c?branch\w*\s+(\.LBB\d+_\d+)', l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            lo = labels[m.group(1)]
-            if sum('s_memtime' in x for x in body[lo:i + 1]) == 6 and (best is None or i - lo < best[1] - best[0]):
-                best = (lo, i)
-    assert best is not None, 'no loop with six stamps found'
-    loop = body[best[0]:best[1] + 1]
-    cuts = [i for i, l in enumerate(loop) if 's_memtime' in l]
-    # phase p = code between stamp p-1 and stamp p; the code after the last stamp wraps around to the first phase (loop edge)
-    segs = [loop[cuts[-1] + 1:] + loop[:cuts[0]]] + [loop[cuts[i] + 1:cuts[i + 1]] for i in range(5)]
-    cols = ['f64 fma', 'f64 mul', 'f64 add', 'f64 other', 'valu other', 'dpp mov', 'accvgpr', 'lds', 'salu', 'store', 'load', 'wait/nop']
+    labels = {re.match(r'^(\.LBB\d+_\d+):', l.strip()).group(1): i for i, l in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', l.strip())}
+    # the step loop: the loop header label in front of a run of NST stamps; its last phase ends at the branch back to that label
+    stamps = [i for i, l in enumerate(body) if 's_memtime' in l]
+    best = None
+    for lab, li in labels.items():
+        inside = [i for i in stamps if i > li][:NST]
+        if len(inside) < NST or any(labels[m] > li and labels[m] <= inside[-1] and 'Loop Header' in body[labels[m]] for m in labels if m != lab):
+            continue
+        back = [i for i, l in enumerate(body) if i > inside[-1] and re.match(r'\s*s_c?branch\w*\s+' + re.escape(lab) + r'\b', l)]
+        if 'Loop Header' in body[li] and back and not [i for i in stamps if li < i < inside[0]]:
+            if best is None or back[0] - li < best[1] - best[0]:
+                best = (li, back[0], inside)
+    assert best is not None, 'no loop with all the stamps found'
+    lo, hi, cuts = best
+    loop = body
+    # phase p = code between stamp p-1 and stamp p; the code after the last stamp (to the back branch) plus the code from the header to the first stamp is the loop edge
+    segs = [loop[cuts[-1] + 1:hi + 1] + loop[lo:cuts[0]]] + [loop[cuts[i] + 1:cuts[i + 1]] for i in range(NST - 1)]
+    cols = ['f64 fma', 'f64 mul', 'f64 add', 'f64 other', 'valu other', 'dpp mov', 'permlane', 'accvgpr', 'lds', 'salu', 'store', 'load', 'wait/nop']
     print(f'{"phase":58s}' + ''.join(f'{c:>11s}' for c in cols) + f'{"VALU":>8s}')
     tot = collections.Counter()
     for name, seg in zip(PHASES, segs):
         c = collections.Counter(classify(l.split()[0]) for l in seg if l.strip() and not l.strip().startswith(('.', ';', '_')) and not l.strip().endswith(':'))
         tot.update(c)
-        valu = sum(c[k] for k in cols[:7])
+        valu = sum(c[k] for k in cols[:8])
         print(f'{name:58s}' + ''.join(f'{c[k]:11d}' for k in cols) + f'{valu:8d}')
-    print(f'{"whole step (static count of the straight-line body)":58s}' + ''.join(f'{tot[k]:11d}' for k in cols) + f'{sum(tot[k] for k in cols[:7]):8d}')
+    print(f'{"whole step (static count of the straight-line body)":58s}' + ''.join(f'{tot[k]:11d}' for k in cols) + f'{sum(tot[k] for k in cols[:8]):8d}')
 
 
 if __name__ == '__main__':

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Run BASELINE config 2 once on the -DUVS_STAMPS build and print the per-phase cycle shares of the tuned kernel.
-usage (GPU box): UVS_LIB_PATH=tools/diag/libuvs_stamps.so python tools/read_stamps.py [lanes]"""
+"""Run BASELINE config 2 once on the -DUVS_STAMPS build and print the per-phase cycle shares of the tuned kernel; --wide: config 5 on the wide kernel.
+usage (GPU box): UVS_LIB_PATH=tools/diag/libuvs_stamps.so python tools/read_stamps.py [lanes | --wide]"""
 import os
 import sys
 
@@ -11,6 +11,32 @@ import torch  # noqa: E402
 import uvs_amd  # noqa: E402
 import bench  # noqa: E402
 
+if '--wide' in sys.argv:                                          # config 5: (32,7), 8 lanes per filter, 8 trials per wavefront, 24 stamp doubles per wavefront
+    T, K, M, N = 65536, 299, 32, 7
+    lin = uvs_amd.LinearPlant.random(M, N, seed=2)
+    rng = np.random.default_rng(5)
+    q_goal = lin.q0 + rng.uniform(-0.3, 0.3, N)
+    fp = uvs_amd.engine.make_params(M, N, 'GMCKF', 10, False, 0.05, 15, 0.2, lin.features(q_goal), False, 0)
+    q0 = torch.as_tensor(q_goal + np.random.default_rng(12345).uniform(-0.15, 0.15, (T, N)), device='cuda')
+    x0 = torch.as_tensor(np.tile((lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel(), (T, 1)), device='cuda')
+    noise = torch.empty((K, T, M), dtype=torch.float64, device='cuda').normal_()
+    for _ in range(2):
+        out = uvs_amd.engine.closed_loop(fp, lin.to_struct('cuda'), q0, noise, x0, want=('x', 'err', 'q'), layout='ktc')
+    torch.cuda.synchronize()
+    stats = out['stats'].cpu().numpy().ravel()
+    waves = T // 8
+    st = np.stack([stats[24 * w: 24 * w + 8] for w in range(waves)])
+    names = ['noise issue + plant + measurement', 'row updates (+ X into the record buffer)', 'record stores', 'Gram + rhs + 36 sums', '(100 MHz wall ticks)',
+             'Cholesky + solve + refinement', 'logs + statistics', 'loop edge']
+    rt = st[:, 4].copy()
+    st[:, 4] = 0
+    tot = st.sum(axis=1)
+    print(f'waves {waves}, cycles per wave: mean {tot.mean():.0f}  min {tot.min():.0f}  max {tot.max():.0f};  per step {tot.mean() / K:.0f}')
+    print(f'shader clock while the kernel runs: {tot.mean() / (rt.mean() / 100e6) / 1e9:.3f} GHz  (loop wall time {rt.mean() / 100e6 * 1e3:.3f} ms per wavefront)')
+    for i, n in enumerate(names):
+        if i != 4:
+            print(f'  {n:44s} {st[:, i].mean() / K:9.0f} cycles/step  {100 * st[:, i].mean() / tot.mean():5.1f}%')
+    sys.exit(0)
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 T, K = 65536, 299
 cfg = bench.config2()

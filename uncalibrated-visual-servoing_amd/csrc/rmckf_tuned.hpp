@@ -558,8 +558,8 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     for (int r = 0; r < R; ++r) {
         if (r * L < N) cmax = fmax(cmax, ((r + 1) * L <= N || r * L + sub < N) ? fabs(a[r][N]) : 0.0);
     }
-    if constexpr (L > 1) cmax = fmax(cmax, dpp_quad<kSwapPair>(cmax));
-    if constexpr (L == 4) cmax = fmax(cmax, dpp_quad<kSwapHalf>(cmax));
+    // (no exchange: a lane's verdict rests on ITS rows of Q^T y -- on lane 0 of the filter, whose mark is the one that is written, global rows
+    // 0, L, 2 L, ...; a smaller denominator only marks sooner, and the healthy fixtures stay five orders of magnitude below the gate)
     const bool grows = spread.grows(smax, cmax);
     // (a column that vanished exactly -- lo == 0 -- sends NaNs through the remaining columns by itself: that trial is marked for the careful
     // second pass, which probes X entry by entry, and is not FAILed here)
@@ -685,13 +685,12 @@ UVS_DEV bool lstsq_tall_emu2(double (&a)[2][N + 1], int sub, double (&sol)[N], b
         rhs = pair_from_dyn<4>(rhs, owner + 2 * hm);
         sol[c] = rhs * rdiag[c];
     }
-    // solution growth: the two-lane kernel's verdict -- the same maxima (global rows 0 .. N-1 of Q^T y: both rows of the h = 0 lanes, row 0 of the h = 1 lanes)
+    // solution growth: the two-lane kernel's verdict -- the same maxima on the lane whose mark is written (global rows < N of its parity: both rows of the h = 0 lane, row 0 of the h = 1 lane)
     double smax = fabs(sol[0]), cmax = fabs(a[0][N]);
 #pragma unroll
     for (int c = 1; c < N; ++c) smax = fmax(smax, fabs(sol[c]));
     cmax = fmax(cmax, high ? 0.0 : fabs(a[1][N]));
-    cmax = fmax(cmax, dpp_quad<kSwapPair>(cmax));
-    cmax = fmax(cmax, dpp_quad<kSwapHalf>(cmax));
+    cmax = fmax(cmax, dpp_quad<kSwapHalf>(cmax));                   // lane 0 of the quad: global rows 0, 2 (its own) and 4 -- the rows of the two-lane kernel's lane 0
     nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
     return spread.suspect() || spread.hi == 0x7ff00000u || spread.grows(smax, cmax);
 }

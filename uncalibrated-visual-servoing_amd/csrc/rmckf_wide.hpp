@@ -233,7 +233,14 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         for (int u = 0; u < N; ++u) { sn[u] = 0.0; cs[u] = 1.0; }
     }
 
+#ifdef UVS_STAMPS                       // diagnostic build: per-phase cycle sums of every wavefront (tools/read_stamps.py --wide); `stats` is garbage then
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    unsigned long long rt_first;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
+#endif
     for (int k = 0; k < K; ++k) {
+        UVS_STAMP(7);                                              // loop edge: joint integration, clock, (DH: sincos advance)
         double nz[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) nz[r] = nz_next[r];
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             err[r] = f - ldes[row];
             lfp[r][lane] = f;
         }
+        UVS_STAMP(0);                                              // noise issue + plant + measurement
         const double sigma = bandwidth(fp, k);
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
         double c_shared = 1.0;
@@ -366,23 +374,37 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 for (int j = 0; j < N; ++j) lt[tl * RECP + (r * L + sub) * N + j] = x[r][j];
             }
         }
+        UVS_STAMP(1);                                              // row updates (+ X into the record buffer)
         UVS_WIDE_FENCE();
-        if constexpr (XOUT && XREC) {
-            if (px) {
-                // the wavefront's TPW records are one contiguous block: lane l stores doubles 2 l, 2 l + 1 of every 128-double (1 KB) slice
-                double *blk = px + 2 * lane;
+        // The wavefront's TPW records are one contiguous block: lane l stores doubles 2 l, 2 l + 1 of every 128-double (1 KB) slice.  Round 5: the
+        // 14 stores no longer leave in one burst behind the rows (the stamped build showed the wavefront waiting 1 600 cycles per step at the full
+        // store queue, and the next step's noise load -- vmcnt counts in order -- behind them): they are handed out in pieces to the control law
+        // below, whose arithmetic they do not touch (the record buffer is rewritten only by the next step's rows).
+        constexpr int NREC = XREC ? TPW * REC / 128 : 0;
+        double *blk = (XOUT && XREC && px) ? px + 2 * lane : nullptr;
+        auto store_records = [&](auto first, auto count) {
+            if constexpr (XOUT && XREC) {
+                if (blk) {
+                    UVS_WIDE_FENCE();
 #pragma unroll
-                for (int i = 0; i < TPW * REC / 128; ++i) {
-                    const double *src = &lt[src_off[i]];
-                    double2 v;
-                    v.x = src[0];
-                    v.y = src[1];
-                    *reinterpret_cast<double2 *>(blk + 128 * i) = v;
+                    for (int i = decltype(first)::value; i < decltype(first)::value + decltype(count)::value && i < NREC; ++i) {
+                        const double *src = &lt[src_off[XREC ? i : 0]];
+                        double2 v;
+                        v.x = src[0];
+                        v.y = src[1];
+                        *reinterpret_cast<double2 *>(blk + 128 * i) = v;
+                    }
+                    UVS_WIDE_FENCE();
                 }
             }
-        }
+        };
+        // Measured A/B on one box (profiles/r05/wide_phase_table.txt): KF 11.18 -> 10.82 ms with the pieces, RMCKF 14.07 -> 14.23 with them -- its lone,
+        // VALU-bound wavefront loses more to the fences that pin the pieces than the queue gives back -- so RMCKF keeps the burst.
+        constexpr bool SPREAD_STORES = SHARED_P;
+        if constexpr (!SPREAD_STORES) store_records(std::integral_constant<int, 0>{}, std::integral_constant<int, NREC>{});
         (void)pxr;
         if (px) px += A.x_out.sk;
+        UVS_STAMP(2);                                              // record stores
         // ---- control law dq = -gain pinv(X)(kappa o err) (experiment.py:300-312): normal equations + one refinement step
         double G[NP], b[N], y[R];
 #pragma unroll
@@ -398,6 +420,12 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
                 for (int j = l; j < N; ++j) G[Sym<N>::at(l, j)] = fma(x[r][l], x[r][j], G[Sym<N>::at(l, j)]);
                 b[l] = fma(x[r][l], y[r], b[l]);
+            }
+            if constexpr (SPREAD_STORES) {
+            if (r == 0) store_records(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            if (r == 1) store_records(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            if (r == 2) store_records(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+            if (r == 3) store_records(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
             }
         }
         if constexpr (L == 8) {                                    // one batch: Gram matrix, right-hand side and the finiteness probe
@@ -420,6 +448,8 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
             for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
         }
+        UVS_STAMP(3);                                              // Gram matrix + right-hand side + their 36 sums over the filter's lanes
+        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
         if (alive && !(chk == 0.0)) {                              // X turned non-finite: pinv would raise (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -431,6 +461,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         const bool suspect = chol_factor<N, DH>(G, rs);          // (wide shape: pivot spread only -- no register left for the column-norm watch, see chol_factor; the (8,6) latency kernel has them)
         flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
         chol_solve_inplace<N>(G, rs, b);                           // s0
+        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 10>{}, std::integral_constant<int, 2>{});
         double c[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) c[j] = 0.0;
@@ -442,6 +473,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
             for (int j = 0; j < N; ++j) c[j] = fma(x[r][j], ri, c[j]);
         }
+        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 12>{}, std::integral_constant<int, (NREC > 12 ? NREC - 12 : 0)>{});
         if constexpr (L == 8) blocked_sums8(c);
         else {
 #pragma unroll
@@ -451,6 +483,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
         for (int j = 0; j < N; ++j) dq[j] = -fp.gain * (b[j] + c[j]);
 
+        UVS_STAMP(5);                                              // Cholesky + solve + refinement (7 more sums) + second solve
         // ---- logs and statistics
         if (pe) {
             double *pc = pe;
@@ -474,6 +507,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             lacc[R + r][lane] += ae;
             lacc[2 * R + r][lane] = fma(t, ae, lacc[2 * R + r][lane]);
         }
+        UVS_STAMP(6);                                              // logs + statistics
         if constexpr (DH) {
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -487,6 +521,17 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         t += fp.dt;
     }
 
+#ifdef UVS_STAMPS
+    {
+        unsigned long long rt_last;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_last)::"memory");
+        stamp_sum[4] = rt_last - rt_first;
+        if (lane == 0 && A.stats) {
+            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
+        }
+        return;
+    }
+#endif
     double s2[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
