@@ -51,16 +51,17 @@ enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
 /* Option bits of uvs_filter_params.reserved.
  * UVS_OPT_STRICT_PINV: every control-law solve of the closed loop / of a replay that asks for the commanded dq goes through the careful
  *   kernels (Householder QR finished by an SVD of the triangular factor with numpy's 1e-15 cutoff, experiment.py:312) instead of only
- *   the trials the fast kernels' rank watch marks.  The watch sees a vanishing pivot and bad column scaling; it cannot see a Jacobian
- *   whose columns are pairwise parallel within ~1e-3 in a cascade (Kahan-like; tests/golden/rankdef_gmckf_kahan_c1000: numpy truncates,
- *   the fast kernels return the plain least-squares command).  Strict mode is about 16 times slower (65 536 trials: 54.7 ms against 3.3); default off. */
+ *   the trials the fast kernels' watches mark.  The watches see a vanishing pivot, bad column scaling and -- since round 5 -- a solution
+ *   that grows by 2^34 against its right-hand side, which also catches the Kahan-like Jacobian (tests/golden/rankdef_gmckf_kahan_c1000) whose
+ *   entries give nothing away; strict mode remains as a cross-check.  It re-runs whole trials through the generic kernel and is an order of
+ *   magnitude slower; default off. */
 #define UVS_OPT_STRICT_PINV 1
-/* Small batches.  A closed-loop batch of the (8,6) shape that does not fill the chip (at most 16 384 trials; KF / IMCC-KF / GMCKF on the DH
- *   plant, lanes_per_filter == 0) runs with four lanes per filter instead of two -- half the trials per wavefront, twice the wavefronts, 17-24 %
- *   less time per launch (8 192 trials: 1.23 -> 0.94 ms on MI355X): what a rank of a strong-scaling split of main.py:121-148 wants.  These
+/* Small batches.  A closed-loop batch of the (8,6) shape that does not fill the chip (at most 16 384 trials; every estimator on the DH
+ *   plant, lanes_per_filter == 0; MCKF too since round 5) runs with four lanes per filter instead of two -- half the trials per wavefront, twice the
+ *   wavefronts, about a fifth less time per launch: what a rank of a strong-scaling split of main.py:121-148 wants.  These
  *   kernels form every sum in the two-lane kernel's order, so the RESULTS ARE BIT-IDENTICAL to the two-lane kernel's: the choice is invisible.
- * UVS_OPT_LATENCY: use the plain four-lane kernels there instead (their own summation order: another 3-13 % faster -- 0.88 ms -- and results
- *   that differ from the default mapping in the last bits; same oracle gates). */
+ * UVS_OPT_LATENCY: use the plain four-lane kernels there instead (their own summation order: a few % faster still, results that differ from the
+ *   default mapping in the last bits; same oracle gates; not for MCKF). */
 #define UVS_OPT_LATENCY 2
 /* UVS_OPT_DIAG_DROP_SEG_FLAG (testing only): in a segmented launch the first segment of every trial chunk does not publish its hand-over
  *   counter, so the chunk's second segment runs out its spin budget (~65 ms) and takes the fallback -- recompute the trial from step 0 --
@@ -140,8 +141,8 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap);
  *   x_final  [T][1][m*n], p_final [T][1][m*n*n] out  state after the last step (NULL to skip)
  *
  * numpy.linalg.pinv semantics (experiment.py:312: SVD, singular values <= 1e-15 * sigma_max dropped).  The kernels solve the control law
- * by Householder least squares, which equals pinv(J) y for full column rank.  Every solve watches the spread of |R_cc|; a trial in which
- * it reaches 2^34 (or a column vanishes) is marked and re-run from its first step by a second, careful kernel that the call enqueues
+ * by Householder least squares, which equals pinv(J) y for full column rank.  Every solve watches the spread of the factor's entries and the
+ * growth of its solution against its right-hand side; a trial in which either reaches 2^34 (or a column vanishes) is marked and re-run from its first step by a second, careful kernel that the call enqueues
  * right behind the first: its control law finishes the QR with a Jacobi SVD of the n x n factor and applies numpy's cutoff, i.e. it
  * returns the truncated minimum-norm command the reference computes for a (numerically) rank-deficient Jacobian.  Healthy trials are not
  * touched by the second pass; the marks never leave the library.

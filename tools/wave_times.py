@@ -26,7 +26,7 @@ cfg['experiments']['epoch'] = T
 cfg['noise']['noise_params']['alpha'] = args.alpha
 K = len(engine.loop_clock(0.05, 15))
 plan = batch.plan_trials(cfg, cells=[args.alpha])
-noise = batch.device_noise(cfg, plan, 0, T, K, dev)
+noise = batch.device_noise(cfg, plan, 0, T, K, dev, share=False)
 q0 = torch.as_tensor(plan.q_start.copy(), device=dev)
 plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
 tpw = 64 // (args.lanes or 2)

@@ -429,10 +429,10 @@ struct Rows {
 //     the trial UVS_STATUS_SUSPECT.  That catches rank deficiency (a vanishing pivot) and bad column scaling, also where the two hide each
 //     other: [[1, 1e20], [0, 1]] has an unremarkable diagonal and condition 1e40 (fixtures tests/golden/rankdef_gmckf_scaled_*: a column
 //     scaled by 1e12 / 1e6 that is parallel to another within 1e-9 / 1e-12 -- numpy truncates, the diagonal alone shows a spread of 1e3).
-//     WHAT NO SUCH WATCH SEES: a factor with every entry of ordinary size whose inverse still explodes (Kahan-like: unit diagonal, all
-//     off-diagonals -1000, condition 3e18; fixture rankdef_gmckf_kahan).  The fast kernels return the plain least-squares command there,
-//     numpy truncates.  It takes columns that are pairwise parallel within 1e-3 in a fixed cascade; callers who must have numpy's answer
-//     there too set UVS_OPT_STRICT_PINV in fp->reserved, which sends EVERY trial through the careful kernels below (about 16 times slower: the generic kernel with an SVD on every solve).
+//     What the spread alone does not see: a factor with every entry of ordinary size whose inverse still explodes (Kahan-like: unit diagonal,
+//     all off-diagonals -1000, condition 3e18; fixture rankdef_gmckf_kahan).  Round 5 added the third watch for it -- the growth of the solution
+//     against its right-hand side (Spread::grows below) -- and the fast kernels mark that trial too; UVS_OPT_STRICT_PINV (every trial through
+//     the careful kernels) remains as a cross-check.
 //     Normal-equation solvers (wide kernel, control wavefronts of the replay) mark at a spread of 2^20 already and are accurate to ~6e-9
 //     in the command up to cond 1e6;
 //   * suspect trials are re-run from their first step by the `careful` instantiation of the generic kernels, launched right behind

@@ -1591,7 +1591,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 asm volatile("" ::: "memory");
             }
 #else
-            if (__any(more)) {                                     // round 4's branch (experiment builds: -DUVS_FPI_SPREAD=0)
+            if (__builtin_expect(__any(more), 0)) {                // round 4's branch (experiment builds: -DUVS_FPI_SPREAD=0), with round 5's cold-branch hint
                 const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
                 bool skip2 = false;
                 double kk[R][N];
