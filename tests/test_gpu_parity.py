@@ -874,6 +874,29 @@ def test_record_layout_gives_the_same_bits(uvs, method, T):
     assert torch.equal(c['err'].view(torch.int64), a['err'].view(torch.int64)) and torch.equal(c['stats'].view(torch.int64), a['stats'].view(torch.int64))
 
 
+@pytest.mark.parametrize('lanes', [0, 8, 16])
+@pytest.mark.parametrize('method', ['KF', 'IMCCKF', 'GMCKF'])
+def test_wide_shape_records_equal_strided_streams(uvs, method, lanes):
+    """(32,7) on the wide kernel: per-trial records (the LDS transposition; since round 5 KF / IMCC-KF hand their record stores out in pieces to the
+    control law) against the trial-fastest layout, 8 and 16 lanes per filter, bit for bit.  tools/fuzz_long.py found the 16-lane KF kernel dropping its
+    last records when the pieces were laid out for four rows per lane only."""
+    import torch
+    M, N, T, K = 32, 7, 40, 37
+    lin = uvs.LinearPlant.random(M, N, seed=2)
+    rng = np.random.default_rng(5)
+    q_goal = lin.q0 + rng.uniform(-0.3, 0.3, N)
+    q0 = _cuda(q_goal + rng.uniform(-0.15, 0.15, (T, N)))
+    x0 = _cuda(np.tile((lin.J * (1 + 0.1 * rng.normal(size=lin.J.shape))).ravel(), (T, 1)))
+    noise = rng.standard_t(3, size=(K, M, T)) * 0.3
+    fp = uvs.engine.make_params(M, N, method, 10, True, 0.05, 15, 0.2, lin.features(q_goal), False, lanes, steps=K)
+    plant = lin.to_struct('cuda')
+    a = uvs.engine.closed_loop(fp, plant, q0, _cuda(noise), x0, want=('x', 'err', 'q'), layout='kct')
+    b = uvs.engine.closed_loop(fp, plant, q0, _cuda(noise.transpose(0, 2, 1)), x0, want=('x', 'err', 'q'), layout='ktc')
+    assert int(a['status'].sum()) == 0 and torch.equal(a['k_done'], b['k_done']) and torch.equal(a['stats'].view(torch.int64), b['stats'].view(torch.int64))
+    for key in ('x', 'err', 'q'):
+        assert torch.equal(uvs.engine.as_tkc(a[key], 'kct').contiguous().view(torch.int64), uvs.engine.as_tkc(b[key], 'ktc').contiguous().view(torch.int64)), key
+
+
 def test_alloc_stream_row_pitch_knob(uvs, monkeypatch):
     """UVS_ROW_PAD pitches the rows of trial-fastest streams; the caller sees the [K][comp][T] view either way."""
     eng = uvs.engine

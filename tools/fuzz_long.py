@@ -90,13 +90,17 @@ def main():
             opts |= 2
         if rng.random() < 0.125:
             opts |= 1
+        if (opts >> 8) > 1 and rng.random() < 0.05:                # round 5: a lost hand-over now and then (the later segment recomputes after its spin budget)
+            opts |= 4
         fp.reserved = opts
+        # round 5: per-trial records for the X stream alone (the XREC instantiations of the (8,6) two-lane KF / IMCC-KF kernels; any other kernel takes the strides)
+        x_layout = 'ktc' if (m == 8 and layout == 'kct' and rng.random() < 0.3) else None
         nz_dev = torch.as_tensor(np.ascontiguousarray(noise.transpose(1, 2, 0) if layout == 'kct' else noise.transpose(1, 0, 2)), device='cuda')
         x0_dev = torch.as_tensor(np.tile(wide['x0'], (T, 1)), device='cuda') if m == 32 else None
-        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), nz_dev, x0_dev, want=('x', 'err', 'q'), layout=layout)
+        out = uvs.engine.closed_loop(fp, plant, torch.as_tensor(q0, device='cuda'), nz_dev, x0_dev, want=('x', 'err', 'q'), layout=layout, x_layout=x_layout)
         st, kd = out['status'].cpu().numpy(), out['k_done'].cpu().numpy()
-        X, E, Q = (uvs.engine.as_tkc(out[k], layout).cpu().numpy() for k in ('x', 'err', 'q'))
-        tag = (case, m, layout, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap, opts)
+        X, E, Q = (uvs.engine.as_tkc(out[k], (x_layout or layout) if k == 'x' else layout).cpu().numpy() for k in ('x', 'err', 'q'))
+        tag = (case, m, layout, x_layout, method, lane, T, K, dt, round(gain, 3), bw, anneal, law, scale, thr, cap, opts)
         n_fail += int((ref['status'] == 1).sum())
         if method == 'MCKF':
             n_multi += int((ref['fpi'] >= 2).sum())

@@ -1809,12 +1809,20 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 
     if constexpr (SEG) {
         if (!last_seg) {                                         // hand the chunk to its next segment: state, then the release of the counter
+            // An item that fell back (its predecessor's counter did not come within the spin budget and it recomputed the trial from step 0) hands
+            // NOTHING over: the chunk's one state slot belongs to the regular chain.  Round 4 let such an item save and publish too; several items
+            // of a chunk falling back at once (they are dispatched together, their budgets run out together) then raced for the slot, and a later
+            // item could restore a state torn between two of them -- found by tools/fuzz_long.py with the counter withheld at 9 segments (round 5).
+            // Its successors run out their own budgets and recompute as well: quadratic work on a path that exists only so that nothing ever hangs.
+            const bool fell_back = fresh && seg > 0;
+            if (!fell_back) {
             seg_state(std::true_type{});
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every write-through store of the wavefront has been acknowledged before ...
             asm volatile("" ::: "memory");
-            // (UVS_OPT_DIAG_DROP_SEG_FLAG: segment 0 keeps its counter to itself, so every second segment runs out its spin budget and recomputes -- tests only)
+            // (UVS_OPT_DIAG_DROP_SEG_FLAG: segment 0 keeps its counter to itself, so every later segment runs out its spin budget and recomputes -- tests only)
             if (lane == 0 && !((A.fp.reserved & UVS_OPT_DIAG_DROP_SEG_FLAG) && seg == 0))
                 __hip_atomic_store(&A.ws_flags[chunk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the counter moves
+            }
 #ifdef UVS_WAVE_TIMES
             if (lane == 0 && A.stats) {
                 unsigned long long wt_last;

@@ -398,6 +398,12 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 }
             }
         };
+        // the NREC stores in R + 3 pieces: one behind every Gram row, one behind the 36 sums, one behind the first solve, one in front of the refinement's
+        // sums -- piece i covers records [i NREC / (R + 3), (i + 1) NREC / (R + 3)) (L = 8: 14 records in 7 pieces of 2; L = 16: 7 records in 5 pieces)
+        auto piece = [&](auto idx) {
+            constexpr int I = decltype(idx)::value, PIECES = R + 3;
+            store_records(std::integral_constant<int, I * NREC / PIECES>{}, std::integral_constant<int, (I + 1) * NREC / PIECES - I * NREC / PIECES>{});
+        };
         // Measured A/B on one box (profiles/r05/wide_phase_table.txt): KF 11.18 -> 10.82 ms with the pieces, RMCKF 14.07 -> 14.23 with them -- its lone,
         // VALU-bound wavefront loses more to the fences that pin the pieces than the queue gives back -- so RMCKF keeps the burst.
         constexpr bool SPREAD_STORES = SHARED_P;
@@ -421,11 +427,12 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
                 for (int j = l; j < N; ++j) G[Sym<N>::at(l, j)] = fma(x[r][l], x[r][j], G[Sym<N>::at(l, j)]);
                 b[l] = fma(x[r][l], y[r], b[l]);
             }
-            if constexpr (SPREAD_STORES) {
-            if (r == 0) store_records(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-            if (r == 1) store_records(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-            if (r == 2) store_records(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-            if (r == 3) store_records(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+            if constexpr (SPREAD_STORES) {                         // piece r of R + 3 (see piece() above)
+                if (r == 0) piece(std::integral_constant<int, 0>{});
+                if (r == 1) piece(std::integral_constant<int, 1>{});
+                if (r == 2) piece(std::integral_constant<int, 2>{});
+                if (r == 3) piece(std::integral_constant<int, 3>{});
+                static_assert(R <= 4, "one piece per Gram row");
             }
         }
         if constexpr (L == 8) {                                    // one batch: Gram matrix, right-hand side and the finiteness probe
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
             for (int j = 0; j < N; ++j) b[j] = group_sum<L>(b[j]);
         }
         UVS_STAMP(3);                                              // Gram matrix + right-hand side + their 36 sums over the filter's lanes
-        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+        if constexpr (SPREAD_STORES) piece(std::integral_constant<int, R>{});
         if (alive && !(chk == 0.0)) {                              // X turned non-finite: pinv would raise (experiment.py:313-316)
             alive = false;
             status = UVS_STATUS_FAIL;
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         const bool suspect = chol_factor<N, DH>(G, rs);          // (wide shape: pivot spread only -- no register left for the column-norm watch, see chol_factor; the (8,6) latency kernel has them)
         flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
         chol_solve_inplace<N>(G, rs, b);                           // s0
-        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 10>{}, std::integral_constant<int, 2>{});
+        if constexpr (SPREAD_STORES) piece(std::integral_constant<int, R + 1>{});
         double c[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) c[j] = 0.0;
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
 #pragma unroll
             for (int j = 0; j < N; ++j) c[j] = fma(x[r][j], ri, c[j]);
         }
-        if constexpr (SPREAD_STORES) store_records(std::integral_constant<int, 12>{}, std::integral_constant<int, (NREC > 12 ? NREC - 12 : 0)>{});
+        if constexpr (SPREAD_STORES) piece(std::integral_constant<int, R + 2>{});
         if constexpr (L == 8) blocked_sums8(c);
         else {
 #pragma unroll
