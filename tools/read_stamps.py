@@ -37,6 +37,31 @@ if '--wide' in sys.argv:                                          # config 5: (3
         if i != 4:
             print(f'  {n:44s} {st[:, i].mean() / K:9.0f} cycles/step  {100 * st[:, i].mean() / tot.mean():5.1f}%')
     sys.exit(0)
+if '--fpi' in sys.argv:                                            # MCKF fixed-point branch by phase (-DUVS_FPI_STAMPS build), whole trials, alpha from argv
+    alpha = float(sys.argv[sys.argv.index('--fpi') + 1]) if len(sys.argv) > sys.argv.index('--fpi') + 1 else 1.0
+    T, K = 65536, 299
+    cfg = bench.config2()
+    cfg['noise']['noise_params']['alpha'] = alpha
+    plan = uvs_amd.batch.plan_trials(cfg, cells=[alpha])
+    fp = uvs_amd.engine.make_params(8, 6, 'MCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 2)
+    fp.reserved = 1 << 8                                           # whole trials: one work item per chunk writes the stamps
+    noise = uvs_amd.batch.device_noise(cfg, plan, 0, T, K, 'cuda', share=False)
+    q0 = torch.as_tensor(plan.q_start, device='cuda')
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    for _ in range(2):
+        out = uvs_amd.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+    torch.cuda.synchronize()
+    stats = out['stats'].cpu().numpy().ravel()
+    waves = T // 32
+    st = np.stack([stats[96 * w: 96 * w + 8] for w in range(waves)])
+    names = ['slot assignment + pull-in', 'park owners blocks + undo + factor', 'park predicted block + passes', 'commit + write-back + X stream', 'pull-back', '(unused)']
+    fir = st[:, 6]
+    print(f'alpha {alpha}: wavefronts {waves}, firings per wavefront mean {fir.mean():.1f} (max {fir.max():.0f}) of {K} steps; step loop {st[:, 7].mean():.0f} cycles per wavefront')
+    tot = st[:, :5].sum(axis=1)
+    print(f'  branch total {tot.sum() / fir.sum():.0f} cycles per firing = {100 * tot.mean() / st[:, 7].mean():.1f} % of the step loop')
+    for i in range(5):
+        print(f'  {names[i]:40s} {st[:, i].sum() / fir.sum():8.0f} cycles per firing')
+    sys.exit(0)
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 T, K = 65536, 299
 cfg = bench.config2()

@@ -50,6 +50,22 @@ namespace uvs {
 #define UVS_STAMP(slot) do { } while (0)
 #endif
 
+// Diagnostic build -DUVS_FPI_STAMPS: cycles of the MCKF fixed-point branch by phase (s_memtime sums per wavefront over the first words of its slice of
+// `stats`, which is garbage in this build; run with whole trials: tools/read_stamps.py --fpi).  Never in the shipped library.
+#ifdef UVS_FPI_STAMPS
+#define UVS_FPI_STAMP(slot)                                                               \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if ((slot) >= 0) fpi_sum[(slot) < 0 ? 0 : (slot)] += now_ - fpi_last;             \
+        fpi_last = now_;                                                                  \
+    } while (0)
+#else
+#define UVS_FPI_STAMP(slot) do { } while (0)
+#endif
+
 // DPP quad_perm move of a double (two 32-bit moves).  CTRL = a | b<<2 | c<<4 | d<<6 selects the source lane of each lane of a quad.
 template <int CTRL>
 UVS_DEV double dpp_quad(double v) {
@@ -1089,6 +1105,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
 #endif
     };
+#ifdef UVS_FPI_STAMPS
+    unsigned long long fpi_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fpi_last = 0, fpi_loop0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fpi_loop0)::"memory");
+#endif
     for (int k = k_begin; k < k_end; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         // (XREC) the records of the PREVIOUS step leave now: their LDS reads and stores have the whole plant phase to drain under -- issued in one
@@ -1447,6 +1467,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 const int rr = EMU2 ? ((g >> 1) & 1) : (g >> 1);                  // owner's local row of global row g ...
                 const int own_off = EMU2 ? (g & 1) + 2 * (g >> 2) : (g & 1);      // ... and the owner's position in its lane group
                 unsigned long long todo = __ballot(more) & (EMU2 ? 0x1111111111111111ull : 0x5555555555555555ull);   // one bit per iterating filter: its first lane
+                UVS_FPI_STAMP(-1);
+#ifdef UVS_FPI_STAMPS
+                fpi_sum[6] += 1;
+#endif
                 while (todo) {                                                    // rounds of up to 8 filters (uniform)
                     int src_even = -1, my_slot = -1;
 #pragma unroll
@@ -1464,47 +1488,83 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     auto pull = [&](int addr, double v) {
                         return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
                     };
-                    // which of the owner's R per-row values belongs to this lane's row: all R candidates pulled, one kept
-                    auto pull_row = [&](const double (&v)[R]) {
-                        double got = pull(sa, v[0]);
-#pragma unroll
-                        for (int r = 1; r < R; ++r) { const double c = pull(sa, v[r]); got = (rr == r) ? c : got; }
-                        return got;
-                    };
                     double *xs = &lds_x[0][0] + ((!XREG && rr < R) ? rr : 0) * (N * 64) + (XREG ? 0 : S);   // the row's X in its owner's LDS column
                     double *ps = &lds_p[0][0] + ((PL > 0 && rr >= PV && rr < R) ? rr - PV : 0) * (NP * 64) + (PL > 0 ? S : 0);   // ... and its parked covariance block (rows >= PV)
-                    double x[N], pp[NP], h[N], kk[N];
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        if constexpr (XREG) {                                     // X in the owner's registers: all R candidates pulled, one kept
-                            double v = pull(sa, xr[0][j]);
-#pragma unroll
-                            for (int r = 1; r < R; ++r) { const double c = pull(sa, xr[XREG ? r : 0][j]); v = (rr == r) ? c : v; }
-                            x[j] = v;
-                        } else {
-                            x[j] = xs[j * 64];
-                        }
-                        h[j] = pull(sa, dq[j]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < NP; ++e) {
-                        double v = (PL > 0) ? ps[e * 64] : 0.0;
-#pragma unroll
-                        for (int r = 0; r < PV; ++r) { const double c = pull(sa, p[r][e]); v = (rr == r) ? c : v; }
-                        pp[e] = v;
-                    }
-                    const double r_gamma = pull_row(m_gamma), r_a = pull_row(m_a), r_nu = pull_row(m_nu), r_z = pull_row(m_z);
-                    // the register-resident blocks of EVERY lane wait out the round in AGPRs (owners get theirs back from the slot, everyone else from here)
+                    // Transport in BATCHES: a lone wavefront at the edge of its registers consumes every ds_bpermute result at once (the first version
+                    // ran with one or two in flight: 10 k cycles for the 128 pulls of a round, -DUVS_FPI_STAMPS).  The owners' register-resident blocks
+                    // are parked in AGPRs FIRST -- that frees the VGPRs the pulls need to overlap -- and are read back one batch at a time as
+                    // bpermute sources; each batch issues all its pulls, then selects.
                     ParkedDouble parked[PV > 0 ? PV : 1][NP];
 #pragma unroll
                     for (int r = 0; r < PV; ++r)
 #pragma unroll
                         for (int e = 0; e < NP; ++e) parked[r][e] = agpr_park(p[r][e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double x[N], pp[NP], h[N], kk[N];
+                    // (then the four undo scalars -- their 4 R sources die with the pulls -- and the command)
+                    double r_gamma, r_a, r_nu, r_z;
+                    {                                                         // the four undo scalars of the row: R candidates each, two batches
+                        auto pull2 = [&](const double (&u)[R], const double (&v)[R], double &ru, double &rv) {
+                            double cu[R], cv[R];
+#pragma unroll
+                            for (int r = 0; r < R; ++r) { cu[r] = pull(sa, u[r]); cv[r] = pull(sa, v[r]); }
+                            __builtin_amdgcn_sched_barrier(0);
+                            ru = cu[0]; rv = cv[0];
+#pragma unroll
+                            for (int r = 1; r < R; ++r) { ru = (rr == r) ? cu[r] : ru; rv = (rr == r) ? cv[r] : rv; }
+                            ru = in_reg(ru); rv = in_reg(rv);                      // (pinned here: LLVM would sink the selects into the row's branch and keep all candidates alive)
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        pull2(m_gamma, m_a, r_gamma, r_a);
+                        pull2(m_nu, m_z, r_nu, r_z);
+                    }
+                    {                                                         // the command (6 doubles)
+                        double c[N];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) c[j] = pull(sa, dq[j]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) h[j] = in_reg(c[j]);
+                    }
+                    constexpr int PB = 7;                                         // doubles per batch: 14 pulls in flight (the counter holds 15)
+#pragma unroll
+                    for (int e = 0; e < NP; ++e) pp[e] = (PL > 0) ? ps[e * 64] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < PV; ++r) {
+#pragma unroll
+                        for (int e0 = 0; e0 < NP; e0 += PB) {
+                            double c[PB];
+#pragma unroll
+                            for (int i = 0; i < PB; ++i)
+                                if (e0 + i < NP) c[i] = pull(sa, agpr_unpark(parked[r][e0 + i]));
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < PB; ++i)
+                                if (e0 + i < NP) pp[e0 + i] = in_reg((rr == r) ? c[i] : pp[e0 + i]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if constexpr (XREG) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            double c[N];
+#pragma unroll
+                            for (int j = 0; j < N; ++j) c[j] = pull(sa, xr[XREG ? r : 0][j]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < N; ++j) x[j] = (r == 0 || rr == r) ? c[j] : x[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) x[j] = xs[j * 64];
+                    }
+                    UVS_FPI_STAMP(0);                                         // slot assignment + parking the owners' blocks + pull-in
                     double Lc[NP], ljj[N];
                     if (act) {
                         mckf_undo_row<N>(x, pp, h, r_gamma, r_a, r_nu, kk);       // back to the prior row and the predicted block
                         mckf_factor_row<N>(pp, Lc, ljj);
                     }
+                    UVS_FPI_STAMP(1);                                         // parking the owners' blocks + undo + factor
                     // (the predicted block is not needed while the row iterates: it waits in AGPRs, like the owners' blocks)
                     ParkedDouble pp_parked[NP];
 #pragma unroll
@@ -1547,6 +1607,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                         const unsigned long long verdict = __ballot(again);
                         more_t = more_t && ((verdict >> ((lane & ~7u) | (unsigned)(M - 1))) & 1ull);
                     }
+                    UVS_FPI_STAMP(2);                                         // parking the predicted block + the passes
 #pragma unroll
                     for (int e = 0; e < NP; ++e) pp[e] = agpr_unpark(pp_parked[e]);
                     if (act) {
@@ -1568,6 +1629,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                             for (int j = 0; j < N; ++j) pxs[j * A.x_out.sc] = x[j];
                         }
                     }
+                    UVS_FPI_STAMP(3);                                         // commit + write-back to LDS + X stream
                     // the register-resident blocks return to their owners
                     const bool is_owner = my_slot >= 0;
                     if constexpr (XREG) {                                         // ... and so does a register-resident X
@@ -1582,12 +1644,20 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     for (int r = 0; r < PV; ++r) {
                         const int ta = ((my_slot < 0 ? 0 : my_slot) * 8 + (EMU2 ? 4 * (sub >> 1) + 2 * r + (sub & 1) : r * L + sub)) << 2;
 #pragma unroll
-                        for (int e = 0; e < NP; ++e) {
-                            const double keep = agpr_unpark(parked[r][e]), c = pull(ta, pp[e]);      // (both unconditionally: straight-line code)
-                            p[r][e] = is_owner ? c : keep;
+                        for (int e0 = 0; e0 < NP; e0 += PB) {                     // batches again: all pulls of a batch in flight, then the selects
+                            double c[PB];
+#pragma unroll
+                            for (int i = 0; i < PB; ++i)
+                                if (e0 + i < NP) c[i] = pull(ta, pp[e0 + i]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < PB; ++i)
+                                if (e0 + i < NP) { const double keep = agpr_unpark(parked[r][e0 + i]); p[r][e0 + i] = is_owner ? c[i] : keep; }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
+                UVS_FPI_STAMP(4);                                             // pull-back of the register-resident blocks (last round)
                 asm volatile("" ::: "memory");
             }
 #else
@@ -1837,6 +1907,17 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             UVS_ITEM_END;
         }
     }
+#ifdef UVS_FPI_STAMPS
+    {
+        unsigned long long end_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(end_)::"memory");
+        fpi_sum[7] = end_ - fpi_loop0;                               // the whole step loop
+        if (lane == 0 && A.stats) {
+            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)fpi_sum[c];
+        }
+        return;
+    }
+#endif
     double s2[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
