@@ -512,7 +512,7 @@ def compact_line(line):
     significant digits.  Contract keys (top level, `config.workload`, `roofline`'s own fields, `cpu_baseline`) are untouched;
     UVS_BENCH_FULL_JSON=<path> writes the unabridged object."""
     prose = ('note', 'binds', 'kernel', 'streams', 'inputs', 'source', 'launches_timed', 'noise_gen_workers', 'latency_option', 'h2d_inclusive_updates_per_s',
-             'launches_while_sampling', 'trials_rank0', 'trials_per_gpu')
+             'launches_while_sampling', 'trials_per_gpu')
     derivable = ('updates_per_s', 'updates_per_launch', 'algorithmic_bytes_per_update', 'unit', 'peak', 'wall_ms', 'updates_total', 'wave_instr_per_s',
                  'fp64_peak_flops', 'per_process_updates_per_s', 'min_kernel_ms', 'layout', 'cells', 'trials_per_cell')
 
@@ -522,7 +522,7 @@ def compact_line(line):
             out = {}
             for k, v in o.items():
                 top = path[0] if path else k
-                if depth > 0 and top != 'cpu_baseline' and (k in prose or k.endswith('_note')) and not (top == 'roofline' and depth == 1 and k == 'kernel'):
+                if depth > 0 and top != 'cpu_baseline' and (k in prose or (k.endswith('_note') and k != 'backend_note')) and not (top == 'roofline' and depth == 1 and k == 'kernel'):
                     continue
                 if k == 'workload' and path != ('config',):
                     continue
@@ -532,7 +532,7 @@ def compact_line(line):
             return out
         if isinstance(o, list):
             return [walk(v, path + ('[]',)) for v in o]
-        if isinstance(o, float) and depth > 1 and not (path[0] == 'roofline' and depth == 2):
+        if isinstance(o, float) and depth > 1 and not (path[0] == 'roofline' and depth == 2) and path[-1] not in ('value', 'ms_per_step'):
             return float(f'{o:.6g}')
         return o
 
