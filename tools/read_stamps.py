@@ -37,6 +37,26 @@ if '--wide' in sys.argv:                                          # config 5: (3
         if i != 4:
             print(f'  {n:44s} {st[:, i].mean() / K:9.0f} cycles/step  {100 * st[:, i].mean() / tot.mean():5.1f}%')
     sys.exit(0)
+if '--items' in sys.argv:                                          # work items of a segmented MCKF launch (-DUVS_ITEM_STAMPS build): entry -> ready -> steps -> handed over
+    alpha = 1.5
+    T, K = 65536, 299
+    cfg = bench.config2()
+    plan = uvs_amd.batch.plan_trials(cfg, cells=[alpha])
+    noise = uvs_amd.batch.device_noise(cfg, plan, 0, T, K, 'cuda', share=False)
+    q0 = torch.as_tensor(plan.q_start, device='cuda')
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    for nseg in (1, 8):
+        fp = uvs_amd.engine.make_params(8, 6, 'MCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 2)
+        fp.reserved = nseg << 8
+        out = uvs_amd.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))          # warm-up (the next call starts from zeroed stats)
+        out = uvs_amd.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+        torch.cuda.synchronize()
+        st = out['stats'].cpu().numpy().ravel()[:8 * nseg].reshape(nseg, 8)
+        print(f'{nseg} segment(s) per trial, {T // 32} chunks; per work item, microseconds (100 MHz wall clock):')
+        for s_ in range(nseg):
+            n = max(st[s_, 3], 1.0)
+            print(f'  segment {s_}: items {int(st[s_, 3])}  entry -> state ready {st[s_, 0] / n / 100:7.1f}   steps {st[s_, 1] / n / 100:7.1f}   save + publish {st[s_, 2] / n / 100:6.1f}')
+    sys.exit(0)
 if '--fpi' in sys.argv:                                            # MCKF fixed-point branch by phase (-DUVS_FPI_STAMPS build), whole trials, alpha from argv
     alpha = float(sys.argv[sys.argv.index('--fpi') + 1]) if len(sys.argv) > sys.argv.index('--fpi') + 1 else 1.0
     T, K = 65536, 299

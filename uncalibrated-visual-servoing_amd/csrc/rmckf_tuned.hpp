@@ -809,6 +809,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     unsigned long long wt_first;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
 #endif
+#ifdef UVS_ITEM_STAMPS                  // diagnostic build: where a work item's time goes (100 MHz wall clock): entry -> state ready -> steps done -> handed over;
+    unsigned long long it_t0, it_t1, it_t2, it_t3;   // summed per segment into the first words of `stats` (garbage there), tools/read_stamps.py --items
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t0)::"memory");
+#endif
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
     const int grp = SPLIT ? (EMU2 ? (sub & 1) : (sub < G ? sub : G - 1)) : 0;   // with L = 4 the fourth lane mirrors group 2 (EMU2: group = parity)
@@ -874,27 +878,39 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     const int K = fp.steps;
     // segment [k_begin, k_end) of the trial; `fresh`: start from the initial state (first segment, or a later one whose predecessor did not
     // report within the spin budget -- it then recomputes the trial from step 0, writing the same rows once more: never a deadlock)
-    int k_begin = 0, k_end = K;
+    int k_begin = 0, k_end = K, flag_early = 0;
     bool fresh = true, last_seg = true;
     if constexpr (SEG) {
         if (A.n_seg > 1) {
             k_begin = A.seg_first[seg];
             k_end = A.seg_first[seg + 1];
             last_seg = seg == A.n_seg - 1;
-            if (seg > 0) {
-                int spins = 0;
-                bool there = false;
-                do {
-                    there = __hip_atomic_load(&A.ws_flags[chunk], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seg;
-                    if (there) break;
-                    __builtin_amdgcn_s_sleep(32);
-                } while (++spins < kSegSpinMax);
-                there = __builtin_amdgcn_readfirstlane((int)there) != 0;          // (every lane ran the acquiring load itself: no further fence)
+            // the predecessor's counter is asked for NOW (relaxed) and looked at after the part of the prologue that does not depend on it --
+            // cursors, plant constants, the first noise rows: an item's start was three memory round trips one after the other (round 5:
+            // 12-15 us from entry to the first step, tools/read_stamps.py --items)
+            if (seg > 0) flag_early = __hip_atomic_load(&A.ws_flags[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    auto await_predecessor = [&]() {
+        if constexpr (SEG) {
+            if (A.n_seg > 1 && seg > 0) {
+                bool there = flag_early >= seg;
+                if (there) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // the state loads below must not be served from lines cached before the counter moved
+                } else {
+                    int spins = 0;
+                    do {
+                        there = __hip_atomic_load(&A.ws_flags[chunk], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seg;
+                        if (there) break;
+                        __builtin_amdgcn_s_sleep(32);
+                    } while (++spins < kSegSpinMax);
+                }
+                there = __builtin_amdgcn_readfirstlane((int)there) != 0;          // (every lane ran the loads itself)
                 fresh = !there;
                 if (fresh) k_begin = 0;
             }
         }
-    }
+    };
 
     // per-lane stream cursors (advance by the step stride once per step; components are reached by adding the uniform stride)
     const double *pn = A.noise.p ? A.noise.at(trial, 0, rb) : nullptr;
@@ -908,6 +924,14 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
 
+    double nz_early[R];                                            // the first noise rows of the segment as planned (a fallback reloads those of step 0)
+    const int k_planned = k_begin;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nz_early[r] = 0.0;
+    if (on_noise && k_planned < K) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz_early[r] = (pn + (long long)k_planned * A.noise.sk)[r * RS * A.noise.sc];
+    }
     if constexpr (DH) {
         if (lane < N) {
             lds_c[PC::kJoint + 5 * lane + 0] = A.plant.theta_offset[lane];
@@ -984,6 +1008,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             }
         }
     };
+    await_predecessor();
     if (!fresh) {
         seg_state(std::false_type{});
     } else {
@@ -1055,11 +1080,19 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         if (!__any(alive)) k_end = k_begin;                      // every trial of the chunk FAILed in an earlier segment
     }
     if (on_noise && k_begin < K) {
+        if (k_begin == k_planned) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) nz_next[r] = pn[r * RS * A.noise.sc];
+            for (int r = 0; r < R; ++r) nz_next[r] = nz_early[r];
+        } else {                                                 // (the fallback: this item starts over at step 0)
+#pragma unroll
+            for (int r = 0; r < R; ++r) nz_next[r] = pn[r * RS * A.noise.sc];
+        }
         pn += A.noise.sk;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
+#ifdef UVS_ITEM_STAMPS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t1)::"memory");
+#endif
 
 #ifdef UVS_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
@@ -1864,6 +1897,9 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int u = 0; u < JG; ++u) q[u] = fma(dq_own[u], fp.dt, q[u]);       // new_q = q + dq t_s (experiment.py:320)
         t += fp.dt;
     }
+#ifdef UVS_ITEM_STAMPS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t2)::"memory");
+#endif
     if constexpr (XREC) { if (k_end > k_begin) store_records(k_end - 1); }   // the last step's records (after a wavefront-wide FAIL: rows past every k_done, unspecified)
 #ifdef UVS_STAMPS
     {
@@ -1904,9 +1940,26 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 ws_[0] = (double)wt_first; ws_[1] = (double)wt_last; ws_[2] = (double)hw_id; ws_[3] = (double)xcc_id;
             }
 #endif
+#ifdef UVS_ITEM_STAMPS
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t3)::"memory");
+            if (lane == 0 && A.stats) {
+                atomicAdd(&A.stats[8 * seg + 0], (double)(it_t1 - it_t0));
+                atomicAdd(&A.stats[8 * seg + 1], (double)(it_t2 - it_t1));
+                atomicAdd(&A.stats[8 * seg + 2], (double)(it_t3 - it_t2));
+                atomicAdd(&A.stats[8 * seg + 3], 1.0);
+            }
+#endif
             UVS_ITEM_END;
         }
     }
+#ifdef UVS_ITEM_STAMPS
+    if (lane == 0 && A.stats) {                                  // the last segment (or a whole trial): no hand-over
+        atomicAdd(&A.stats[8 * seg + 0], (double)(it_t1 - it_t0));
+        atomicAdd(&A.stats[8 * seg + 1], (double)(it_t2 - it_t1));
+        atomicAdd(&A.stats[8 * seg + 3], 1.0);
+    }
+    return;
+#endif
 #ifdef UVS_FPI_STAMPS
     {
         unsigned long long end_;
