@@ -302,16 +302,6 @@ UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&Lc)[Sym<N>::N
         xcv[l] = xc[l];
     }
 }
-// Round 4's form (experiment builds with -DUVS_FPI_SPREAD=0): factor, iterate and accumulate in one call, once per pass.
-template <int N>
-UVS_DEV void mckf_iterate_row(const double (&x)[N], const double (&pp)[Sym<N>::NP], const double (&h)[N], double zi, double neg_half_inv_s2,
-                              const double (&k)[N], double (&kn)[N], double &num, double &den, bool &bad) {
-    double Lc[Sym<N>::NP], ljj[N], dd[N], xcv[N];
-    mckf_factor_row<N>(pp, Lc, ljj);
-    mckf_iterate_row<N>(x, Lc, ljj, h, zi, neg_half_inv_s2, k, kn, dd, xcv, bad);
-#pragma unroll
-    for (int l = 0; l < N; ++l) { num = fma(dd[l], dd[l], num); den = fma(xcv[l], xcv[l], den); }
-}
 // Final state of a row after the iteration: x + k nu0 and the Joseph form with a gain row that is no longer gamma (P + Q) h
 // (experiment.py:297): P - k g^T - g k^T + (h.g + 1) k k^T, g = (P + Q) h.
 template <int N>
@@ -749,9 +739,6 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 // scratch inside the step loop); at 1 it takes 270 registers, no scratch, and is faster at every size measured (profiles/r04/shard_times.txt:
 // 8 192 trials 0.97 -> 0.90 ms, 16 384: 1.26 -> 1.00, 32 768: 2.06 -> 1.88).  Four lanes per filter are the LATENCY mapping (UVS_OPT_LATENCY):
 // half the trials per wavefront, 14 % fewer instructions per wavefront-step -- the shards of a strong-scaling series that do not fill the chip.
-#ifndef UVS_FPI_SPREAD                  // experiment builds: 0 = round 4's fixed-point branch (rows iterate on their two owner lanes)
-#define UVS_FPI_SPREAD 1
-#endif
 #ifndef UVS_L4_OCC
 #define UVS_L4_OCC 1
 #endif
@@ -1479,9 +1466,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 fpi.den = pair_sum<L>(fpi.den);
             }
             const double thr2 = fp.fpi_threshold * fp.fpi_threshold;
-            int it = 1;
             bool more = alive && !fpi.skip && !fpi.poison && (fpi.num > thr2 * fpi.den);  // ||Xc - X|| / ||X|| > threshold; NaN ends the iteration like the reference's while
-#if UVS_FPI_SPREAD
             if (__builtin_expect(__any(more), 0)) {
                 // ---- the fixed-point branch, spread over the wavefront (round 5).  Round 4 ran it where the state lives: the two lanes of an
                 // iterating filter worked through their four rows each while the other 62 lanes of the wavefront waited (a firing cost ~3 800 issue
@@ -1693,87 +1678,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 UVS_FPI_STAMP(4);                                             // pull-back of the register-resident blocks (last round)
                 asm volatile("" ::: "memory");
             }
-#else
-            if (__builtin_expect(__any(more), 0)) {                // round 4's branch (experiment builds: -DUVS_FPI_SPREAD=0), with round 5's cold-branch hint
-                const bool redo = more;                              // pair-uniform: both lanes of a filter take the same path
-                bool skip2 = false;
-                double kk[R][N];
-                if (redo) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {                    // undo the optimistic commit
-                        double x[N], pb[NP];
-#pragma unroll
-                        for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
-#pragma unroll
-                        for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-                        mckf_undo_row<N>(x, pb, dq, m_gamma[r], m_a[r], m_nu[r], kk[r]);
-#pragma unroll
-                        for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
-#pragma unroll
-                        for (int e = 0; e < NP; ++e) {
-                            if (r < PV) p[r < PV ? r : 0][e] = pb[e];
-                            else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
-                        }
-                    }
-                }
-                while (__any(more)) {
-                    double kn[R][N], num2 = 0.0, den2 = 0.0;
-                    bool bad2 = false;
-                    if (more) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            double x[N], pb[NP];
-#pragma unroll
-                            for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
-#pragma unroll
-                            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-                            mckf_iterate_row<N>(x, pb, dq, m_z[r], neg_half_inv_s2, kk[r], kn[r], num2, den2, bad2);
-                        }
-                        num2 = pair_sum<L>(num2);
-                        den2 = pair_sum<L>(den2);
-                        const bool hit_zero = pair_sum<L>(bad2 ? 1.0 : 0.0) != 0.0;
-                        if (hit_zero) {                              // inv(Cy) raises: the correction of this step is skipped (:231-236)
-                            skip2 = true;
-                            more = false;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < R; ++r)
-#pragma unroll
-                                for (int j = 0; j < N; ++j) kk[r][j] = kn[r][j];
-                            ++it;
-                            if (it == fp.fpi_epoch_max) skip2 = true;                                    // :246-250
-                            more = !skip2 && (num2 > thr2 * den2) && it < fp.fpi_epoch_max;
-                        }
-                    }
-                }
-                if (redo) {
-                    double *pxs = px - UVS_SK(A.x_out.sk);           // this step's rows of the X stream: overwrite the optimistic values
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        double x[N], pb[NP];
-#pragma unroll
-                        for (int j = 0; j < N; ++j) x[j] = lds_x[r * N + j][lane];
-                        if (!skip2) {
-#pragma unroll
-                            for (int e = 0; e < NP; ++e) pb[e] = (r < PV) ? p[r < PV ? r : 0][e] : lds_p[(r >= PV ? r - PV : 0) * NP + e][lane];
-                            mckf_commit_row<N>(x, pb, dq, m_z[r], kk[r], chk);
-#pragma unroll
-                            for (int j = 0; j < N; ++j) lds_x[r * N + j][lane] = x[j];
-#pragma unroll
-                            for (int e = 0; e < NP; ++e) {
-                                if (r < PV) p[r < PV ? r : 0][e] = pb[e];
-                                else lds_p[(r >= PV ? r - PV : 0) * NP + e][lane] = pb[e];
-                            }
-                        }
-                        if constexpr (XOUT) {
-#pragma unroll
-                            for (int j = 0; j < N; ++j) pxs[((long long)r * L * N + j) * A.x_out.sc] = x[j];
-                        }
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
-#endif
         }
         if constexpr (METHOD == UVS_METHOD_MCKF && XREG && !EMU2) {   // plain register-resident variants (L = 1, 4): first pass only, the rest to the careful pass
             fpi.num = pair_sum<L>(fpi.num);
