@@ -609,10 +609,11 @@ def test_full_size_batch_properties(uvs):
 
 def test_full_size_config2_product_noise_all_299_steps(uvs):
     """BASELINE config 2 exactly as bench.py runs it (VERDICT r3 #7a): 65 536 trials on the PRODUCT's alpha = 1.5 generator, global seeds
-    123456 + t and jitter draws (main.py:121-139).  24 trials spread over the grid are compared with oracle/c over ALL 299 steps on host
-    noise of the same global indices (NoiseProfiler streams; the device generator matches them to 2e-13).  Heavy tails make a few closed
-    loops amplify rounding: such trials are identified by the oracle itself, re-run from starts moved by 1e-14, and held to
-    status / k_done only; at least 16 of the 24 must be calm and within 1e-8."""
+    123456 + t and jitter draws (main.py:121-139), noise through the shared T + 70-stream buffer (round 5).  536 trials spread over the grid
+    (every 128th and the edges of wavefronts / rounds; round 4 sampled 24) are compared with oracle/c over ALL 299 steps on host noise of the
+    same global indices (NoiseProfiler streams; the device generator matches them to 2e-13).  Heavy tails make a few closed loops amplify
+    rounding: such trials are identified by the oracle itself, re-run from starts moved by 1e-14, and held to status /
+    k_done only; at least 70 % of the sample must be calm and within 1e-8."""
     import torch
     import bench
     from oracle import c_oracle
@@ -620,7 +621,7 @@ def test_full_size_config2_product_noise_all_299_steps(uvs):
     cfg = bench.config2()
     res = uvs.batch.run_batch(cfg, cells=[1.5], want=('err', 'q'))
     assert res.stats.shape == (T, 3) and len(res.plan) == T and int(res.plan.seed[0]) == 123456
-    sample = np.array([0, 1, 31, 32, 63, 64, 1000, 4097, 8191, 12345, 16384, 20000, 30001, 32767, 32768, 40000, 44444, 50000, 54321, 60000, 65000, 65503, 65534, 65535])
+    sample = np.unique(np.concatenate([np.arange(0, T, 128), [0, 1, 31, 32, 63, 64, 1000, 4097, 8191, 12345, 16384, 20000, 30001, 32767, 32768, 40000, 44444, 50000, 54321, 60000, 65000, 65503, 65534, 65535]]))
     noise = np.zeros((len(sample), K, 8))
     for i, t in enumerate(sample):
         uvs.batch.trial_noise(cfg, res.plan, int(t), int(t) + 1, K, noise[i:i + 1])
@@ -641,7 +642,7 @@ def test_full_size_config2_product_noise_all_299_steps(uvs):
         assert rel_err(q[:kd, :, int(t)].cpu().numpy(), ref['q'][i, :kd]) <= 1e-8, int(t)
         if status[t] == 0:
             assert np.abs(stats[t] - ref['stats'][i]).max() / ref['stats'][i].max() <= 1e-8, int(t)
-    assert calm >= 16, calm
+    assert len(sample) >= 530 and calm >= 0.7 * len(sample), (calm, len(sample))
     # the launch that bench.py times is this one: same failed-trial count as the bench line reports for the headline
     assert int((status != 0).sum()) < T // 1000
 
