@@ -22,6 +22,7 @@ struct NoiseArgs {
     const unsigned long long *states;      // [T][n_gen][4]: state_hi, state_lo, inc_hi, inc_lo
     const double *zig;                     // fi[256], wi[256], ki[256] (ki as raw u64 bits)
     View out;
+    int chunks = 1, draws_per_sample = 0;  // noise_streams_kernel: lanes per stream and PCG64 draws per sample (0 = not fixed: one chunk)
 };
 
 struct Pcg64 {
@@ -39,6 +40,34 @@ struct Pcg64 {
         return (x >> rot) | (x << ((64u - rot) & 63u));
     }
     UVS_DEV double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+    // The generator `delta` draws further on, in O(log delta) 128-bit multiply-adds (the LCG jump of pcg64.h, pcg_advance_lcg_128): lets several
+    // lanes share ONE stream, each starting at its own step (noise_streams_kernel).
+    UVS_DEV void advance(unsigned long long delta) {
+        auto mul = [](unsigned long long ah, unsigned long long al, unsigned long long bh, unsigned long long bl, unsigned long long &rh, unsigned long long &rl) {
+            rl = al * bl;
+            rh = __umul64hi(al, bl) + al * bh + ah * bl;
+        };
+        unsigned long long cmh = 0x2360ED051FC65DA4ULL, cml = 0x4385DF649FCCF645ULL, cph = ih, cpl = il;      // current multiplier / increment
+        unsigned long long amh = 0, aml = 1, aph = 0, apl = 0;                                                // accumulated multiplier / increment
+        while (delta) {
+            if (delta & 1ULL) {
+                mul(amh, aml, cmh, cml, amh, aml);
+                unsigned long long th, tl;
+                mul(aph, apl, cmh, cml, th, tl);
+                apl = tl + cpl;
+                aph = th + cph + (apl < tl ? 1ULL : 0ULL);
+            }
+            unsigned long long mh = cmh, ml = cml + 1ULL;                                                       // (cur_mult + 1) * cur_plus
+            mh += (ml == 0ULL) ? 1ULL : 0ULL;
+            mul(mh, ml, cph, cpl, cph, cpl);
+            mul(cmh, cml, cmh, cml, cmh, cml);
+            delta >>= 1;
+        }
+        unsigned long long th, tl;
+        mul(amh, aml, sh, sl, th, tl);
+        sl = tl + apl;
+        sh = th + aph + (sl < tl ? 1ULL : 0ULL);
+    }
 };
 
 // numpy's integer seed -> PCG64 stream, on the device.  SeedSequence (numpy/random/bit_generator.pyx): the seed's 32-bit words
@@ -261,13 +290,21 @@ __global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_streams_kernel(const N
     static_assert(TYPE == UVS_NOISE_WHITE || TYPE == UVS_NOISE_ALPHA_STABLE || TYPE == UVS_NOISE_UNIFORM || TYPE == kNoiseStableSymmetric,
                   "one generator per feature");
     const uvs_noise_params &p = A.np;
-    const long long s = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (s >= A.T) return;
+    const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
+    // A.chunks lanes share a stream (stream fastest: a wavefront still writes 512 contiguous bytes per step), each generating its own range of
+    // steps from the generator jumped ahead -- only where a sample takes a FIXED number of draws (A.draws_per_sample: 2 for the Chambers-Mallows-
+    // Stuck transform, 1 for uniform and Cauchy; the ziggurat normal does not, and runs with one chunk).  T + 70 streams are 1 026 wavefronts, one
+    // per SIMD and nothing to overlap with: in four chunks the same work runs four wavefronts deep.
+    const long long s = gid % A.T;
+    const int chunk = (int)(gid / A.T);
+    if (chunk >= A.chunks) return;
+    const int per = (p.steps + A.chunks - 1) / A.chunks, k0 = chunk * per, k1 = (k0 + per < p.steps) ? k0 + per : p.steps;
     Pcg64 g[1], sel;
     g[0].load(A.states + s * 4);
     sel.sh = sel.sl = sel.ih = sel.il = 0;                    // unused
-    double *o = A.out.p + s * A.out.st;
-    for (int k = 0; k < p.steps; ++k) {
+    if (k0 > 0) g[0].advance((unsigned long long)A.draws_per_sample * (unsigned long long)k0);
+    double *o = A.out.p + s * A.out.st + (long long)k0 * A.out.sk;
+    for (int k = k0; k < k1; ++k) {
         *o = draw<TYPE>(p, g, sel, A.zig);
         o += A.out.sk;
     }

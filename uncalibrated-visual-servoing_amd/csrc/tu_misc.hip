@@ -49,7 +49,23 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
 
 void uvs_launch::noise_streams(const uvs_noise_params &np, long long S, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
     uvs::NoiseArgs A{np, S, states, zig, out};
-    const dim3 g((unsigned)((S + 63) / 64));
+    // draws per sample of the type's generator (noise.py:179-205): uniform and Cauchy 1, the Chambers-Mallows-Stuck transform 2 (V, W); the ziggurat
+    // normal (white noise, alpha = 2, the Levy case) consumes a data-dependent number and keeps one lane per stream
+    int draws = 0;
+    if (np.type == UVS_NOISE_UNIFORM) draws = 1;
+    else if (np.type == UVS_NOISE_ALPHA_STABLE) {
+        if (np.alpha == 2.0 || (np.alpha == 0.5 && (np.beta == 1.0 || np.beta == -1.0))) draws = 0;
+        else draws = (np.alpha == 1.0 && np.beta == 0.0) ? 1 : 2;
+    }
+    A.draws_per_sample = draws;
+    A.chunks = 1;
+    if (draws > 0 && S > 0) {                                     // aim at ~4 wavefronts per SIMD, at least 8 steps per chunk
+        long long c = (4096LL * 64 + S - 1) / S;
+        if (c > 8) c = 8;
+        if (c > np.steps / 8) c = np.steps / 8;
+        A.chunks = c < 1 ? 1 : (int)c;
+    }
+    const dim3 g((unsigned)((S * A.chunks + 63) / 64));
     switch (np.type) {
         case UVS_NOISE_WHITE: hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_WHITE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_ALPHA_STABLE:
