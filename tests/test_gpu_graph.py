@@ -202,3 +202,57 @@ def test_replay_and_statistics_are_graph_capturable(uvs):
         a, b = cap[key], eager[key]
         assert torch.equal(a, b) if a.dtype == torch.int32 else torch.equal(_bits(a), _bits(b)), key
     assert torch.equal(_bits(stats), _bits(eager_stats))
+
+
+def test_sweep_cell_with_shared_noise_is_one_graph(uvs):
+    """A whole sweep cell -- device seeding (uvs_pcg64_seed_u64), the T + 70 shared noise streams in chunks (uvs_noise_generate_streams_f64, round 5)
+    and the closed loop reading them through the overlapping view -- captured as ONE graph; replays return the bits of the eager pipeline, and with
+    another seed vector in the static input buffer those of the eager pipeline on those seeds."""
+    import torch
+    import bench
+    nd = uvs.noise_device
+    cfg = bench.config2()
+    T, K, M = 333, 80, 8
+    des = cfg['experiments']['desired_f']
+    plant = uvs.SyntheticPlant.ur10(des).to_struct()
+    fp = uvs.engine.make_params(8, 6, 'GMCKF', 10.0, False, 0.05, 15.0, 0.2, des, True, 2, K)
+    plan = uvs.batch.plan_trials(cfg, cells=[1.5], epoch=T)
+    q0 = torch.as_tensor(plan.q_start.copy(), device='cuda')
+    params = dict(alpha=1.5, beta=0, gamma=1, delta=0)
+    S = T + nd.SEED_STEP * (M - 1)
+    q = nd.make_noise_params(uvs.NoiseType.ALPHA_STABLE, params, M, K)
+    zig = nd._zig('cuda')
+
+    def eager(seed0):
+        _, view = nd.generate_shared(uvs.NoiseType.ALPHA_STABLE, params, seed0, T, M, K)
+        return uvs.engine.closed_loop(fp, plant, q0, view, want=('x', 'err'))
+
+    ref_a, ref_b = eager(123456), eager(777)
+    torch.cuda.synchronize()
+    seeds = torch.empty(S, dtype=torch.int64, device='cuda')
+    states = torch.empty((S, 4), dtype=torch.int64, device='cuda')
+    buf = torch.empty((K, S), dtype=torch.float64, device='cuda')
+    view = torch.as_strided(buf, (K, M, T), (S, nd.SEED_STEP, 1))
+    x = uvs.engine.alloc_stream(T, K, 48); err = uvs.engine.alloc_stream(T, K, 8)
+    stats = torch.zeros((T, 3), dtype=torch.float64, device='cuda')
+    status = torch.zeros(T, dtype=torch.int32, device='cuda'); k_done = torch.zeros(T, dtype=torch.int32, device='cuda')
+    sv, NV, View = uvs.engine.stream_view, uvs.engine.NULL_VIEW, uvs.engine.View
+    flat = lambda t: View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc1 = uvs.lib().uvs_pcg64_seed_u64(S, seeds.data_ptr(), states.data_ptr(), st)
+        rc2 = uvs.lib().uvs_noise_generate_streams_f64(C.byref(q), S, states.data_ptr(), zig.data_ptr(), buf.data_ptr(), 1, S, st)
+        rc3 = uvs.engine.launch_closed_loop(fp, plant, T, flat(q0), sv(view), NV, sv(x), sv(err), NV, NV, NV,
+                                            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, device=q0.device)
+    assert (rc1, rc2, rc3) == (0, 0, 0), uvs.lib().uvs_last_error()
+    for seed0, ref in ((123456, ref_a), (777, ref_b), (123456, ref_a)):
+        seeds.copy_(torch.arange(S, dtype=torch.int64, device='cuda') + seed0)
+        for t in (x, err, stats, buf):
+            t.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(status, ref['status']) and torch.equal(k_done, ref['k_done']) and int(status.sum()) == 0
+        assert torch.equal(_bits(x), _bits(ref['x'])) and torch.equal(_bits(err), _bits(ref['err'])) and torch.equal(_bits(stats), _bits(ref['stats']))
