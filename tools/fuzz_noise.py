@@ -18,7 +18,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     NT = uvs.NoiseType
-    bad, worst, n = [], 0.0, 0
+    bad, worst, n, n_shared = [], 0.0, 0, 0
     t0 = time.time()
     for case in range(cases):
         kind = [NT.WHITE_NOISE, NT.GAUSSIAN_MIXTURE, NT.GAUSSIAN_BIMODAL, NT.ALPHA_STABLE, NT.UNIFORM][case % 5]
@@ -43,6 +43,15 @@ def main():
         dev = uvs.engine.as_tkc(uvs.noise_device.generate(kind, params, seeds, m, K, hold, hold_cnt, layout=layout, device='cuda'), layout).cpu().numpy()
         n += host.size
         tag = (case, kind.name, params, m, T, K, hold, hold_cnt, layout)
+        # round 5: where the trials' streams alias (consecutive seeds, one generator per feature, no hold) the shared-stream generator -- T + 10 (m - 1)
+        # streams once, in chunks behind a PCG64 jump -- must return the per-trial generator's bits
+        if uvs.noise_device.shares_streams(kind, hold, seeds):
+            _, view = uvs.noise_device.generate_shared(kind, params, int(seeds[0]), T, m, K)
+            same = np.array_equal(view.permute(2, 0, 1).cpu().numpy().view(np.int64), np.ascontiguousarray(dev).view(np.int64))
+            n_shared += 1
+            if not same:
+                bad.append(('shared streams differ from per-trial streams', tag))
+                continue
         if not np.all(np.isfinite(host) == np.isfinite(dev)):
             bad.append(('finite pattern', tag))
             continue
@@ -60,7 +69,7 @@ def main():
                 bad.append(('tolerance', tag, float(d.max())))
             worst = max(worst, float(np.median(d)) if len(d) else 0.0)
         if case % 50 == 49:
-            print(f'{case + 1} cases, {n / 1e6:.1f} M samples, {len(bad)} mismatches, {time.time() - t0:.0f} s', flush=True)
+            print(f'{case + 1} cases ({n_shared} also through the shared-stream generator), {n / 1e6:.1f} M samples, {len(bad)} mismatches, {time.time() - t0:.0f} s', flush=True)
     for b in bad[:30]:
         print('MISMATCH', b)
     print('done:', cases, 'cases,', f'{n / 1e6:.1f} M samples,', len(bad), 'mismatches')
