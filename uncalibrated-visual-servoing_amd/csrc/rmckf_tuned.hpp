@@ -1100,7 +1100,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         fair_slot = hw_id_ & 1u;                                 // WAVE_ID bit 0
     }
     auto store_records = [&](int k) {                            // XREC: the records of step k, straight out of the LDS-resident X
-#ifndef UVS_XREC_DIRECT
         if constexpr (XREC) {
             // The wavefront's 32 records of this step are 12 KB of contiguous memory.  Store a = 0..3, b = 0..2: lane (tg, pp) = (lane / 8, lane % 8)
             // writes pair 8 b + pp (two consecutive components, 16 bytes) of trial 8 a + tg -- eight trials x 128 contiguous bytes per instruction.
@@ -1123,7 +1122,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
             }
         }
-#endif
     };
 #ifdef UVS_FPI_STAMPS
     unsigned long long fpi_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fpi_last = 0, fpi_loop0;
@@ -1421,14 +1419,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 if constexpr (XREG) xr[r][j] = x[j];
                 else lds_x[r * N + j][lane] = x[j];
             }
-#ifdef UVS_XREC_DIRECT                  // experiment: records written from the rows' own registers, 16 bytes per lane and store (no LDS transposition)
-            if constexpr (XREC) {
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                double *rr_ = A.x_out.p + (long long)k * A.x_out.sk + trial * (long long)(M * N) + (r * RS + rb) * N;
-#pragma unroll
-                for (int j = 0; j < N; j += 2) { v2d v; v.x = x[j]; v.y = x[j + 1]; *reinterpret_cast<v2d *>(rr_ + j) = v; }
-            }
-#endif
             if constexpr (XOUT && !XREC) {
 #ifdef UVS_ABLATE_STORES
                 if (k == K - 1)
