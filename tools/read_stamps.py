@@ -55,7 +55,7 @@ if '--items' in sys.argv:                                          # work items 
         print(f'{nseg} segment(s) per trial, {T // 32} chunks; per work item, microseconds (100 MHz wall clock):')
         for s_ in range(nseg):
             n = max(st[s_, 3], 1.0)
-            print(f'  segment {s_}: items {int(st[s_, 3])}  entry -> state ready {st[s_, 0] / n / 100:7.1f}   steps {st[s_, 1] / n / 100:7.1f}   save + publish {st[s_, 2] / n / 100:6.1f}')
+            print(f'  segment {s_}: items {int(st[s_, 3])}  entry -> state ready {st[s_, 0] / n / 100:7.1f}   steps {st[s_, 1] / n / 100:7.1f}   save + publish {st[s_, 2] / n / 100:6.1f}   (entry -> predecessor seen {st[s_, 4] / n / 100:5.1f}, state restored after another {st[s_, 5] / n / 100:5.1f})')
     sys.exit(0)
 if '--fpi' in sys.argv:                                            # MCKF fixed-point branch by phase (-DUVS_FPI_STAMPS build), whole trials, alpha from argv
     alpha = float(sys.argv[sys.argv.index('--fpi') + 1]) if len(sys.argv) > sys.argv.index('--fpi') + 1 else 1.0
