@@ -395,113 +395,48 @@ def power_under_load(torch, launch, device_index, max_seconds=10.0):
 
 
 def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU):
-    """What main.py:104-196 does for one sweep, end to end on the GPU (side object, never `value`): for each of the reference's 12 cells
-    alpha = linspace(1, 2, 12) -- device seeding + noise generation, closed loop with X / err / q logged, D2H of the per-trial
-    [ISE, IAE, ITAE, status, k_done] rows -- at `trials_per_cell` trials per cell.  Timed twice: cell after cell on one stream, and with
-    the noise of cell c + 1 generated on a second stream while the closed loop of cell c runs."""
-    import ctypes as C
+    """What main.py:104-196 does for one sweep, end to end on the GPU (side object, never `value`): the product's own sweep driver,
+    batch.run_sweep -- for each of the reference's 12 cells alpha = linspace(1, 2, 12): device seeding + noise generation, closed loop
+    with the per-step streams logged on the device, the per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory on
+    a second stream -- at `trials_per_cell` trials per cell, timed by its host clock (synchronised on both sides)."""
     cfg = config2()
     cfg['experiments']['epoch'] = trials_per_cell
-    plan = batch.plan_trials(cfg)                                  # 12 cells x trials_per_cell, global seeds / jitter draws
-    cells = plan.cells
-    T, K, M, N = trials_per_cell, len(engine.loop_clock(0.05, 15)), 8, 6
-    fp = engine.make_params(M, N, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
-    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
-    NV = uvs_amd._lib.NULL_VIEW
-    flat = lambda t: uvs_amd._lib.View(t.data_ptr(), t.stride(0), 0, t.stride(1))     # noqa: E731
-    bufs = {k: engine.alloc_stream(T, K, c, 'kct', dev) for k, c in (('x', M * N), ('err', M), ('q', N), ('f', M))}
-    noise = [engine.alloc_stream(T, K, M, 'kct', dev) for _ in range(2)]
-    rows_dev = [torch.zeros((T, 5), dtype=torch.float64, device=dev) for _ in range(2)]
-    rows_host = torch.empty((len(cells), T, 5), dtype=torch.float64).pin_memory()
-    stats = torch.zeros((T, 3), dtype=torch.float64, device=dev)
-    status = torch.zeros(T, dtype=torch.int32, device=dev)
-    k_done = torch.zeros(T, dtype=torch.int32, device=dev)
-    q0_all = torch.as_tensor(plan.q_start.copy(), device=dev)
-    nt = uvs_amd.NoiseType.ALPHA_STABLE
-    seeds_dev = torch.as_tensor(np.asarray(plan.seed, dtype=np.uint64).view(np.int64), device=dev)     # every cell's seeds, uploaded once
-
-    S = T + uvs_amd.noise_device.SEED_STEP * (M - 1)              # distinct streams of a cell: seeds seed0 + c T ... + T + 70 (noise.py:70, main.py:139)
-    shared = [torch.empty((K, S), dtype=torch.float64, device=dev) for _ in range(2)]
-    assert uvs_amd.noise_device.shares_streams(nt, False, plan.seed[:T])
-    dense_gen = [False]                                           # True: every trial's 8 streams generated separately (round 4's path), for the comparison
-
-    def gen(c, buf):
-        """Noise of cell c; returns the [step][feature][trial] tensor the closed loop reads (buf itself, or the overlapping view of shared[.])."""
-        params = dict(alpha=float(cells[c]), beta=0, gamma=1, delta=0)
-        if dense_gen[0]:
-            uvs_amd.noise_device.generate(nt, params, seeds_dev[c * T:(c + 1) * T], M, K, False, 0, 'kct', out=buf, device=dev)
-            return buf
-        slot = 0 if buf is noise[0] else 1
-        return uvs_amd.noise_device.generate_shared(nt, params, int(plan.seed[c * T]), T, M, K, out=shared[slot], device=dev)[1]
-
-    def loop(c, buf, slot, csv=False):
-        # csv: the per-step streams results.csv holds (main.py:152-194: error, q, f; the camera pose follows from q, the noise is the input) --
-        # the Jacobian estimate X, 384 of the headline's 560 B per update, is not among them
-        rc = engine.launch_closed_loop(fp, plant, T, flat(q0_all[c * T:(c + 1) * T]), engine.stream_view(buf, 'kct'), NV,
-            NV if csv else engine.stream_view(bufs['x'], 'kct'), engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'),
-            engine.stream_view(bufs['f'], 'kct') if csv else NV, NV,
-            stats.data_ptr(), status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev)
-        uvs_amd._lib.check(rc)
-        r = rows_dev[slot]
-        r[:, :3] = stats
-        r[:, 3] = status
-        r[:, 4] = k_done
-        rows_host[c].copy_(r, non_blocking=True)
-
-    def serial():
-        for c in range(len(cells)):
-            loop(c, gen(c, noise[0]), 0)
-        torch.cuda.synchronize()
-
-    def serial_dense():
-        dense_gen[0] = True
-        try:
-            serial()
-        finally:
-            dense_gen[0] = False
-
-    def serial_csv():
-        for c in range(len(cells)):
-            loop(c, gen(c, noise[0]), 0, csv=True)
-        torch.cuda.synchronize()
-
-    side = torch.cuda.Stream(device=dev)
-
-    def overlapped():
-        main = torch.cuda.current_stream()
-        ready = [torch.cuda.Event() for _ in cells]
-        freed = [torch.cuda.Event() for _ in cells]
-        for c in range(len(cells)):
-            with torch.cuda.stream(side):
-                if c >= 2:
-                    side.wait_event(freed[c - 2])                  # the buffer's previous cell has been consumed
-                view = gen(c, noise[c % 2])
-                ready[c].record(side)
-            main.wait_event(ready[c])
-            loop(c, view, c % 2)
-            freed[c].record(main)
-        torch.cuda.synchronize()
-
+    variants = (('one_stream', dict(want=('x', 'err', 'q'))),                       # the headline's streams
+                ('one_stream_csv_streams', dict(want=('err', 'q', 'f'))),           # what results.csv holds per step (main.py:152-194): 176 B per update
+                ('stats_only', dict(want=())),                                      # per-trial rows only
+                ('one_stream_every_stream_generated', dict(want=('x', 'err', 'q'), share_noise=False)))     # round 4's path: 8 T streams instead of T + 70
     out = {}
-    for name, fn in (('one_stream', serial), ('noise_on_second_stream', overlapped), ('one_stream_csv_streams', serial_csv), ('one_stream_every_stream_generated', serial_dense)):
-        fn()                                                       # warm-up (allocator, tables)
-        t0 = time.perf_counter()
-        fn()
-        wall = time.perf_counter() - t0
-        rows = rows_host.numpy()
-        updates = int(rows[:, :, 4].sum())
-        out[name] = {'wall_ms': wall * 1e3, 'ms_per_cell': wall * 1e3 / len(cells), 'updates_per_s': updates / wall, 'failed_trials': int((rows[:, :, 3] != 0).sum())}
-    # the pieces on their own (events on one stream), for the breakdown
+    for name, kw in variants:
+        batch.run_sweep(cfg, device=dev, **kw)                     # warm-up (allocator, tables)
+        r = batch.run_sweep(cfg, device=dev, **kw)
+        updates = int(r.k_done.sum())
+        out[name] = {'wall_ms': r.seconds * 1e3, 'ms_per_cell': r.seconds * 1e3 / len(r.pieces), 'updates_per_s': updates / r.seconds,
+                     'failed_trials': int((r.status != 0).sum())}
+    # the pieces of one cell on their own (events on one stream), for the breakdown
+    T, K, M = trials_per_cell, len(engine.loop_clock(0.05, 15)), 8
+    plan = r.plan
+    fp = engine.make_params(M, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
+    plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    q0 = torch.as_tensor(plan.q_start[5 * T:6 * T].copy(), device=dev)
+    params = dict(alpha=float(plan.cells[5]), beta=0, gamma=1, delta=0)
     ev = lambda: torch.cuda.Event(enable_timing=True)             # noqa: E731
-    a, b, c_, d = ev(), ev(), ev(), ev()
-    a.record(); v5 = gen(5, noise[0]); b.record(); loop(5, v5, 0); c_.record()
-    torch.cuda.synchronize()
-    out['breakdown_one_cell_ms'] = {'seeding_and_noise_generation': a.elapsed_time(b), 'closed_loop_kernel_and_row_copy': b.elapsed_time(c_)}
-    out.update(workload=f'the reference sweep of main.py:104-148: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), X+err+q logged on the device, '
-                        'per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory', cells=len(cells), trials_per_cell=T, updates_total=updates,
+    res = None
+    for _ in range(2):
+        a, b, c_ = ev(), ev(), ev()
+        a.record()
+        view = uvs_amd.noise_device.generate_shared(uvs_amd.NoiseType.ALPHA_STABLE, params, int(plan.seed[5 * T]), T, M, K, device=dev)[1]
+        b.record()
+        res = engine.closed_loop(fp, plant, q0, view, want=('x', 'err', 'q'), reuse=res)
+        c_.record()
+        torch.cuda.synchronize()
+    out['breakdown_one_cell_ms'] = {'seeding_and_noise_generation': a.elapsed_time(b), 'closed_loop_kernel': b.elapsed_time(c_)}
+    out.update(workload=f'the reference sweep of main.py:104-148 through batch.run_sweep: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), '
+                        'per-step streams logged on the device, per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory',
+               cells=len(r.pieces), trials_per_cell=T, updates_total=updates,
                note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell; never part of `value`.  '
-                    'one_stream_csv_streams: the same sweep logging what results.csv holds per step (err, q, f: 176 B per update written) instead of X + err + q')
-    del bufs, noise
+                    'one_stream: X + err + q logged (the headline\'s streams); one_stream_csv_streams: err, q, f (what results.csv holds per step, '
+                    '176 B per update); stats_only: no per-step stream; one_stream_every_stream_generated: without the stream aliasing (8 T streams)')
+    del res, view
     torch.cuda.empty_cache()
     return out
 

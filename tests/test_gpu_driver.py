@@ -99,3 +99,35 @@ def test_run_batch_launch_options(uvs):
     for r in (base, lat, strict):
         assert int(r.status.sum()) == 0 and r.stats.shape == (300, 3)
     assert 'strict_pinv' not in cfg and 'latency' not in cfg['experiments'] and 'latency' not in cfg['estimator']
+
+
+@pytest.mark.parametrize('method,noise_type,hold', [('GMCKF', 'ALPHA_STABLE', False), ('MCKF', 'ALPHA_STABLE', False), ('GMCKF', 'GAUSSIAN_MIXTURE', True)])
+def test_run_sweep_is_run_batch_cell_after_cell(uvs, method, noise_type, hold):
+    """batch.run_sweep (pieces through one set of buffers, rows copied out on a second stream) returns run_batch's per-trial rows bit for bit:
+    ragged pieces (cells of 150 trials cut at 64), shared and per-trial noise generation, a rank's shard that starts inside a cell."""
+    cfg = _cfg(method, epoch=150)
+    if noise_type != 'ALPHA_STABLE':
+        cfg['noise'].update(type=noise_type, hold=hold, hold_time=0.5, noise_params=dict(std=1.0, mean=50.0, rho=0.1))
+    cells = [1.0, 1.3, 2.0] if noise_type == 'ALPHA_STABLE' else [0.0, 0.1, 0.2]
+    whole = uvs.batch.run_batch(cfg, cells=cells, want=('err',))
+    for rank, world in ((0, 1), (1, 4)):
+        seen = []
+        sw = uvs.batch.run_sweep(cfg, cells=cells, rank=rank, world=world, want=('err',), max_trials=64,
+                                 on_piece=lambda a, b, c, out: seen.append((a, b, c, out['err'].clone())))
+        lo, hi = sw.lo, sw.hi
+        assert (lo, hi) == uvs.dist.shard_range(450, rank, world) and [p[:2] for p in sw.pieces] == [s[:2] for s in seen]
+        assert all(b - a <= 64 and len(set(whole.plan.cell[a:b])) == 1 for a, b, _ in sw.pieces) and sum(b - a for a, b, _ in sw.pieces) == hi - lo
+        assert np.array_equal(sw.stats, whole.stats.cpu().numpy()[lo:hi]) and np.array_equal(sw.status, whole.status.cpu().numpy()[lo:hi])
+        assert np.array_equal(sw.k_done, whole.k_done.cpu().numpy()[lo:hi])
+        kd = whole.k_done.cpu().numpy()
+        for a, b, c, err in seen:
+            ref = whole.streams['err'][:, :, a:b].cpu().numpy()
+            got = err.cpu().numpy()
+            for j in range(b - a):                                     # rows at and after k_done are unspecified
+                assert np.array_equal(got[:kd[a + j], :, j], ref[:kd[a + j], :, j])
+        assert sw.rows().shape == (hi - lo, 5) and sw.seconds > 0
+    full = uvs.batch.run_sweep(cfg, cells=cells)                       # no streams, whole cells, no callback: the pipelined form
+    assert np.array_equal(full.stats, whole.stats.cpu().numpy()) and np.array_equal(full.status, whole.status.cpu().numpy())
+    s_a = full.cell_summary()
+    s_b = uvs.stats.cell_summary(whole.stats.cpu().numpy(), whole.status.cpu().numpy(), whole.plan.cell)
+    assert s_a == s_b or all(np.allclose([s_a[c][k] for k in s_a[c]], [s_b[c][k] for k in s_b[c]], equal_nan=True) for c in s_a)

@@ -179,6 +179,130 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
                        start.elapsed_time(stop) * 1e-3)
 
 
+def sweep_pieces(plan, lo, hi, max_trials=None):
+    """[(a, b, cell)]: this shard's trials [lo, hi) cut at the cell boundaries (main.py:121-127: a cell is a contiguous run of trials) and,
+    when ``max_trials`` is given, into pieces of at most that many trials -- the launches of run_sweep, in trial order."""
+    out, a = [], lo
+    while a < hi:
+        c = int(plan.cell[a])
+        b = a + int(np.searchsorted(plan.cell[a:hi], c, side='right'))
+        if max_trials:
+            b = min(b, a + int(max_trials))
+        out.append((a, b, c))
+        a = b
+    return out
+
+
+@dataclass
+class SweepResult:
+    """Per-trial rows of a shard of the sweep on the HOST (pinned memory): what main.py keeps of a trial once its CSV rows are written."""
+    plan: TrialPlan
+    lo: int
+    hi: int
+    stats: np.ndarray        # (T_local, 3)  ||ISE||_2, ||IAE||_2, ||ITAE||_2
+    status: np.ndarray       # (T_local,) int32
+    k_done: np.ndarray       # (T_local,) int32
+    pieces: list
+    seconds: float = 0.0     # wall clock of the whole sweep, synchronised on both sides
+
+    def rows(self):
+        """(T_local, 5) fp64 [ISE, IAE, ITAE, status, k_done]."""
+        return np.concatenate([self.stats, self.status[:, None].astype(float), self.k_done[:, None].astype(float)], axis=1)
+
+    def cell_summary(self):
+        from . import stats as _stats
+        return _stats.cell_summary(self.stats, self.status, self.plan.cell[self.lo:self.hi])
+
+
+def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(), lanes=0, device='cuda', max_trials=None,
+              share_noise=True, on_piece=None, strict_pinv=False, latency=False):
+    """The whole sweep of main.py:104-148 on this rank's GPU, cell after cell through ONE set of device buffers: for each piece (a cell, or
+    ``max_trials`` trials of it) device seeding + noise generation (the T + 70 distinct streams where they alias), the closed-loop launch,
+    and the per-trial [ISE, IAE, ITAE], status, k_done copied to pinned host memory on a second stream while the next piece computes.
+    Device memory is that of the largest piece, whatever the sweep's size; results are bit-identical to ``run_batch`` over the same trials
+    (same global seeds and jitter draws; a rank of ``world`` owns the contiguous global trials of dist.shard_range).
+
+    ``want``: per-step streams to log on the device; they live until the next piece overwrites them, so ``on_piece(a, b, cell, out)`` --
+    called after the piece has finished, with engine.closed_loop's dict -- is where a sink consumes them (it serialises the pipeline)."""
+    import time
+    import torch
+    cfg = load_config(cfg)
+    ex, est, nz = cfg['experiments'], cfg['estimator'], cfg['noise']
+    method = Method[est['method']]
+    if method == Method.ANALYTICAL:
+        raise NotImplementedError('ANALYTICAL is not an estimator (and crashes in the reference: R is unbound, experiment.py:121)')
+    plant = SyntheticPlant.ur10(ex['desired_f']) if plant is None else plant
+    plan = plan_trials(cfg, cells, epoch)
+    lo, hi = dist.shard_range(len(plan), rank, world)
+    p = est['estimator_params']
+    m, n = len(ex['desired_f']), plant.n_joints
+    fp = engine.make_params(m, n, method.name, p.get('kernel_bw', 1.0), p.get('annealing', False), ex['dt'], ex['t_max'],
+                            ex['ibvs_gain'], ex['desired_f'], p['initial_guess'], lanes, None, p.get('fpi_threshold', 0.1),
+                            p.get('fpi_epoch_max', 1000))
+    fp.reserved = (1 if strict_pinv else 0) | (2 if latency else 0)
+    K = len(engine.loop_clock(ex['dt'], ex['t_max']))
+    dev = torch.device(device)
+    pieces = sweep_pieces(plan, lo, hi, max_trials)
+    Tl = hi - lo
+    host = dict(stats=torch.empty((Tl, 3), dtype=torch.float64).pin_memory(), status=torch.empty(Tl, dtype=torch.int32).pin_memory(),
+                k_done=torch.empty(Tl, dtype=torch.int32).pin_memory())
+    if not pieces:
+        return SweepResult(plan, lo, hi, host['stats'].numpy(), host['status'].numpy(), host['k_done'].numpy(), pieces)
+    Tmax = max(b - a for a, b, _ in pieces)
+    noise_type = NoiseType[nz['type']]
+    hold_cnt = int(nz['hold_time'] / ex['dt'])                      # main.py:137
+    key = 'alpha' if noise_type == NoiseType.ALPHA_STABLE else 'rho'
+    plant_struct = plant.to_struct()
+    q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
+    x0 = None
+    if not p['initial_guess']:
+        x0 = torch.as_tensor(np.asarray(p['x0'], float).reshape(1, m * n).repeat(Tmax, 0), device=dev)
+    seeds_dev = torch.as_tensor(np.ascontiguousarray(plan.seed[lo:hi], dtype=np.uint64).view(np.int64), device=dev)
+    # two sets of per-trial outputs (a set is copied out while the next piece writes the other), one set of streams, one noise buffer
+    S = Tmax + noise_device.SEED_STEP * (m - 1)
+    noise_buf = torch.empty(K * max(S, m * Tmax), dtype=torch.float64, device=dev)
+    sets = []
+    for _ in range(2):
+        d = {k_: engine.alloc_stream(Tmax, K, c, 'kct', dev) for k_, c in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)) if k_ in want}
+        d.update(stats=torch.zeros((Tmax, 3), dtype=torch.float64, device=dev), status=torch.zeros(Tmax, dtype=torch.int32, device=dev),
+                 k_done=torch.zeros(Tmax, dtype=torch.int32, device=dev))
+        sets.append(d)
+    for k_ in want:                                                # the streams are not double-buffered (7.5 GB of X per 65 536 trials)
+        sets[1][k_] = sets[0][k_]
+    main, copier = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    copied = []
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i, (a, b, c) in enumerate(pieces):
+        T = b - a
+        params = dict(nz['noise_params'])
+        params[key] = float(plan.cells[c])                          # main.py:123-126
+        if share_noise and noise_device.shares_streams(noise_type, nz['hold'], plan.seed[a:b]):
+            St = T + noise_device.SEED_STEP * (m - 1)
+            noise = noise_device.generate_shared(noise_type, params, int(plan.seed[a]), T, m, K, out=noise_buf[:K * St].view(K, St), device=dev)[1]
+        else:
+            noise = noise_buf[:K * m * T].view(K, m, T)
+            noise_device.generate(noise_type, params, seeds_dev[a - lo:b - lo], m, K, nz['hold'], hold_cnt, 'kct', out=noise, device=dev)
+        if i >= 2:
+            main.wait_event(copied[i - 2])                          # this set's previous rows have left the device
+        out = engine.closed_loop(fp, plant_struct, q0[a - lo:b - lo], noise, None if x0 is None else x0[:T], want=want, reuse=sets[i % 2])
+        done = torch.cuda.Event()
+        done.record(main)
+        copier.wait_event(done)
+        with torch.cuda.stream(copier):
+            for k_ in ('stats', 'status', 'k_done'):
+                host[k_][a - lo:b - lo].copy_(out[k_], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copier)
+        copied.append(ev)
+        if on_piece is not None:
+            done.synchronize()
+            on_piece(a, b, c, out)
+    torch.cuda.synchronize(dev)
+    seconds = time.perf_counter() - t0
+    return SweepResult(plan, lo, hi, host['stats'].numpy(), host['status'].numpy(), host['k_done'].numpy(), pieces, seconds)
+
+
 CSV_COLUMNS = (['experiment_id', 'status', 'rho', 't'] + [f'q_{i}' for i in range(1, 7)] +
                ['camera_x', 'camera_y', 'camera_z', 'camera_roll', 'camera_pitch', 'camera_yaw'] +
                [f'f_{i}' for i in range(1, 9)] + [f'desired_f_{i}' for i in range(1, 9)] + [f'noise_{i}' for i in range(1, 9)] + ['kernel_bw'])

@@ -118,21 +118,33 @@ def launch_closed_loop(fp, plant_struct, T, *args, device=None):
     return _lib.lib().uvs_rmckf_closed_loop_ws_f64(C.byref(fp), C.byref(plant_struct), T, *args, ws, ws_bytes, _stream())
 
 
-def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False, x_layout=None):
+def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False, x_layout=None, reuse=None):
     """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
     ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``).
     ``x_layout``: another layout for the X stream alone -- 'ktc' (per-trial records) is the fast store path of the (8,6) KF / IMCC-KF / RMCKF
-    kernels, whatever the layout of the narrow streams (which are coalesced as trial-fastest rows)."""
+    kernels, whatever the layout of the narrow streams (which are coalesced as trial-fastest rows).
+    ``reuse``: the dict an earlier call with at least as many trials returned -- its tensors are written again ([..., :T] of the streams,
+    [:T] of the per-trial arrays) instead of allocating new ones (batch.run_sweep: cell after cell through one set of buffers)."""
     x_layout = x_layout or layout
     torch = _torch()
     T, K, m, n = q_start.shape[0], fp.steps, fp.m, fp.n
     dev = q_start.device
     out = {}
+    tdim = lambda lay: {'kct': 2, 'ktc': 1, 'tkc': 0}[lay]         # noqa: E731
     for key, comp in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)):
-        out[key] = alloc_stream(T, K, comp, x_layout if key == 'x' else layout, dev) if key in want else None      # rows at and after k_done are unspecified
-    out['stats'] = torch.zeros((T, 3), dtype=torch.float64, device=dev)
-    out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
-    out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
+        lay = x_layout if key == 'x' else layout
+        if key not in want:
+            out[key] = None
+        elif reuse is not None:
+            out[key] = reuse[key].narrow(tdim(lay), 0, T)
+        else:
+            out[key] = alloc_stream(T, K, comp, lay, dev)          # rows at and after k_done are unspecified
+    if reuse is not None:
+        out['stats'], out['status'], out['k_done'] = reuse['stats'][:T], reuse['status'][:T], reuse['k_done'][:T]
+    else:
+        out['stats'] = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+        out['status'] = torch.zeros(T, dtype=torch.int32, device=dev)
+        out['k_done'] = torch.zeros(T, dtype=torch.int32, device=dev)
     out['x_final'] = torch.empty((T, m * n), dtype=torch.float64, device=dev) if final_state else None
     out['p_final'] = torch.empty((T, m * n * n), dtype=torch.float64, device=dev) if final_state else None
     flat = lambda t: NULL_VIEW if t is None else View(t.data_ptr(), t.stride(0), 0, t.stride(1))      # noqa: E731
