@@ -433,7 +433,8 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     out.update(workload=f'the reference sweep of main.py:104-148 through batch.run_sweep: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), '
                         'per-step streams logged on the device, per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory',
                cells=len(r.pieces), trials_per_cell=T, updates_total=updates,
-               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell; never part of `value`.  '
+               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell, and the clock ramp of a sweep that starts on an idle GPU '
+                    '(profiles/r05/sweep_trace.txt); never part of `value`.  '
                     'one_stream: X + err + q logged (the headline\'s streams); one_stream_csv_streams: err, q, f (what results.csv holds per step, '
                     '176 B per update); stats_only: no per-step stream; one_stream_every_stream_generated: without the stream aliasing (8 T streams)')
     del res, view

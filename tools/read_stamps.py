@@ -82,12 +82,18 @@ if '--fpi' in sys.argv:                                            # MCKF fixed-
     for i in range(5):
         print(f'  {names[i]:40s} {st[:, i].sum() / fir.sum():8.0f} cycles per firing')
     sys.exit(0)
-lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+alpha = float(sys.argv[sys.argv.index('--alpha') + 1]) if '--alpha' in sys.argv else None      # --alpha A: the sweep's alpha-stable noise instead of N(0, 1)
+pos = [a for a in sys.argv[1:] if not a.startswith('--') and (sys.argv[sys.argv.index(a) - 1] != '--alpha')]
+lanes = int(pos[0]) if pos else 2
 T, K = 65536, 299
 cfg = bench.config2()
-plan = uvs_amd.batch.plan_trials(cfg, cells=[1.5])
+plan = uvs_amd.batch.plan_trials(cfg, cells=[alpha or 1.5])
 fp = uvs_amd.engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, lanes)
-noise = torch.empty((K, 8, T), dtype=torch.float64, device='cuda').normal_()
+if alpha is None:
+    noise = torch.empty((K, 8, T), dtype=torch.float64, device='cuda').normal_()
+else:
+    cfg['noise']['noise_params']['alpha'] = alpha
+    noise = uvs_amd.batch.device_noise(cfg, plan, 0, T, K, 'cuda', share=False)
 q0 = torch.as_tensor(plan.q_start, device='cuda')
 plant = uvs_amd.SyntheticPlant.ur10().to_struct()
 for _ in range(2):
