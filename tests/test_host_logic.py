@@ -374,3 +374,22 @@ def test_reference_streams_alias_across_trials(uvs, base, shifted):
     streams = uvs.noise_batch(nt, a['meta']['noise_params'], a['meta']['seed'] + np.arange(S), m, K)[:, :, 0]     # feature 0 of S trials
     for i in range(m):
         assert np.array_equal(dense[:, :, i], streams[10 * i:10 * i + len(seeds)])
+
+
+def test_sweep_pieces_cover_a_shard_cell_by_cell():
+    """batch.sweep_pieces: a shard's trials in order, cut at the cell boundaries (main.py:121-127) and at max_trials."""
+    from uvs_amd import batch, dist
+    cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'config_reference.json')))
+    cfg['experiments']['epoch'] = 150
+    plan = batch.plan_trials(cfg)                                  # 12 cells x 150 trials
+    for world in (1, 4, 7):
+        for rank in range(world):
+            lo, hi = dist.shard_range(len(plan), rank, world)
+            for cap in (None, 64, 150, 1000):
+                pieces = batch.sweep_pieces(plan, lo, hi, cap)
+                assert [a for a, _, _ in pieces] == [lo] + [b for _, b, _ in pieces[:-1]] and pieces[-1][1] == hi
+                for a, b, c in pieces:
+                    assert a < b and set(plan.cell[a:b]) == {c} and (cap is None or b - a <= cap)
+                if cap is None or cap >= 150:                        # whole cells: one piece per cell the shard touches
+                    assert len(pieces) == len(set(plan.cell[lo:hi]))
+    assert batch.sweep_pieces(plan, 5, 5) == []
