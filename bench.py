@@ -406,15 +406,15 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
                 ('stats_only', dict(want=())),                                      # per-trial rows only
                 ('one_stream_every_stream_generated', dict(want=('x', 'err', 'q'), share_noise=False)))     # round 4's path: 8 T streams instead of T + 70
     out = {}
-    for name, kw in variants:
-        batch.run_sweep(cfg, device=dev, **kw)                     # warm-up (allocator, tables)
-        r = batch.run_sweep(cfg, device=dev, **kw)
+    plan = batch.plan_trials(cfg)                                  # once: planning 786 432 trials on the host takes 0.3 s, and a GPU left idle that long
+    for name, kw in variants:                                      # starts the sweep at a low clock (profiles/r05/sweep_trace.txt)
+        batch.run_sweep(cfg, device=dev, plan=plan, **kw)          # warm-up (allocator, tables)
+        r = batch.run_sweep(cfg, device=dev, plan=plan, **kw)
         updates = int(r.k_done.sum())
         out[name] = {'wall_ms': r.seconds * 1e3, 'ms_per_cell': r.seconds * 1e3 / len(r.pieces), 'updates_per_s': updates / r.seconds,
                      'failed_trials': int((r.status != 0).sum())}
     # the pieces of one cell on their own (events on one stream), for the breakdown
     T, K, M = trials_per_cell, len(engine.loop_clock(0.05, 15)), 8
-    plan = r.plan
     fp = engine.make_params(M, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
     plant = uvs_amd.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
     q0 = torch.as_tensor(plan.q_start[5 * T:6 * T].copy(), device=dev)
@@ -433,8 +433,8 @@ def e2e_sweep(torch, uvs_amd, engine, batch, dev, trials_per_cell=TRIALS_PER_GPU
     out.update(workload=f'the reference sweep of main.py:104-148 through batch.run_sweep: 12 cells alpha = linspace(1, 2, 12) x {T} trials x {K} updates, GMCKF(RMCKF), '
                         'per-step streams logged on the device, per-trial [ISE, IAE, ITAE, status, k_done] rows copied to pinned host memory',
                cells=len(r.pieces), trials_per_cell=T, updates_total=updates,
-               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell, and the clock ramp of a sweep that starts on an idle GPU '
-                    '(profiles/r05/sweep_trace.txt); never part of `value`.  '
+               note='end to end, inputs NOT resident: includes device seeding and noise generation of every cell (the trial plan is made once, before: a sweep that '
+                    'starts on an idle GPU spends its first cells at a lower clock, profiles/r05/sweep_trace.txt); never part of `value`.  '
                     'one_stream: X + err + q logged (the headline\'s streams); one_stream_csv_streams: err, q, f (what results.csv holds per step, '
                     '176 B per update); stats_only: no per-step stream; one_stream_every_stream_generated: without the stream aliasing (8 T streams)')
     del res, view

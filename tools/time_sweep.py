@@ -14,14 +14,15 @@ cfg['experiments']['epoch'] = T
 if len(sys.argv) > 2:
     cfg['estimator']['method'] = sys.argv[2]
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+plan = uvs_amd.batch.plan_trials(cfg)
 i = -1
 for want in ((), ('err', 'q', 'f'), ('x', 'err', 'q')):
     for share in (True, False):
         i += 1
         if only is not None and i != only:
             continue
-        uvs_amd.batch.run_sweep(cfg, want=want, share_noise=share)            # warm-up (allocator, tables)
+        uvs_amd.batch.run_sweep(cfg, want=want, share_noise=share, plan=plan)            # warm-up (allocator, tables)
         for _ in range(3):
-            r = uvs_amd.batch.run_sweep(cfg, want=want, share_noise=share)
+            r = uvs_amd.batch.run_sweep(cfg, want=want, share_noise=share, plan=plan)
             print(f'{cfg["estimator"]["method"]} want={want} shared_noise={share}: {r.seconds * 1e3 / 12:.3f} ms per cell, {int(r.k_done.sum()) / r.seconds / 1e9:.2f} G updates/s, '
                   f'failed {int((r.status != 0).sum())}', flush=True)
