@@ -179,6 +179,9 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
                        start.elapsed_time(stop) * 1e-3)
 
 
+_COPY_STREAMS = {}
+
+
 def sweep_pieces(plan, lo, hi, max_trials=None):
     """[(a, b, cell)]: this shard's trials [lo, hi) cut at the cell boundaries (main.py:121-127: a cell is a contiguous run of trials) and,
     when ``max_trials`` is given, into pieces of at most that many trials -- the launches of run_sweep, in trial order."""
@@ -270,7 +273,12 @@ def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(),
         sets.append(d)
     for k_ in want:                                                # the streams are not double-buffered (7.5 GB of X per 65 536 trials)
         sets[1][k_] = sets[0][k_]
-    main, copier = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    copier = _COPY_STREAMS.get(str(dev))                           # one per device, kept: the first use of a new stream costs ~4 ms on the host
+    if copier is None:                                             # (queue creation), during which the GPU runs dry
+        copier = _COPY_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(copier):
+            torch.zeros(1, device=dev)
     copied = []
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
