@@ -24,11 +24,17 @@ def main():
     cfg = json.load(open(args.config))
     cfg.pop('_about', None)
     cfg['estimator']['method'] = args.method
-    want = ('err', 'q', 'f') if args.csv else ('err',)
-    uvs_amd.batch.run_batch(cfg, epoch=1, want=want)            # warm-up: loads the code object, uploads the ziggurat tables
-    res = uvs_amd.batch.run_batch(cfg, epoch=args.epoch, want=want)
-    summary = uvs_amd.stats.cell_summary(res.stats.cpu().numpy(), res.status.cpu().numpy(), res.plan.cell)
-    print(f'{len(res.plan)} trials in {res.seconds * 1e3:.2f} ms of kernel time ({args.method})')
+    if args.csv:                                                 # every trial's per-step streams stay on the device for the CSV writer: one grid
+        want = ('err', 'q', 'f')
+        uvs_amd.batch.run_batch(cfg, epoch=1, want=want)        # warm-up: loads the code object, uploads the ziggurat tables
+        res = uvs_amd.batch.run_batch(cfg, epoch=args.epoch, want=want)
+        summary = uvs_amd.stats.cell_summary(res.stats.cpu().numpy(), res.status.cpu().numpy(), res.plan.cell)
+        print(f'{len(res.plan)} trials in {res.seconds * 1e3:.2f} ms of kernel time ({args.method})')
+    else:                                                        # statistics only: cell after cell through one set of buffers, any epoch
+        uvs_amd.batch.run_sweep(cfg, epoch=1)
+        res = uvs_amd.batch.run_sweep(cfg, epoch=args.epoch)
+        summary = res.cell_summary()
+        print(f'{len(res.plan)} trials in {res.seconds * 1e3:.2f} ms end to end: seeding, noise, closed loop, rows on the host ({args.method})')
     for c, row in summary.items():
         print(f'alpha = {res.plan.cells[c]:.4f}  ok {row["success"]:4d}/{row["trials"]:4d}  ITAE mean {row["itae_mean"]:12.1f}  std {row["itae_std"]:12.1f}  median {row["itae_median"]:12.1f}')
     if args.csv:
