@@ -607,8 +607,10 @@ def test_full_size_batch_properties(uvs):
     assert int((full['status'] != 0).sum()) < T // 100
 
 
-def test_full_size_config2_product_noise_all_299_steps(uvs):
-    """BASELINE config 2 exactly as bench.py runs it (VERDICT r3 #7a): 65 536 trials on the PRODUCT's alpha = 1.5 generator, global seeds
+@pytest.mark.parametrize('method,max_failed', [('GMCKF', 65), ('MCKF', 1000), ('KF', 65), ('IMCCKF', 65)])
+def test_full_size_config2_product_noise_all_299_steps(uvs, method, max_failed):
+    """BASELINE config 2 exactly as bench.py runs it (VERDICT r3 #7a), and (round 5) the same launch for the other three estimators -- MCKF
+    as the library's 8 tapered work items per trial at full size: 65 536 trials on the PRODUCT's alpha = 1.5 generator, global seeds
     123456 + t and jitter draws (main.py:121-139), noise through the shared T + 70-stream buffer (round 5).  536 trials spread over the grid
     (every 128th and the edges of wavefronts / rounds; round 4 sampled 24) are compared with oracle/c over ALL 299 steps on host noise of the
     same global indices (NoiseProfiler streams; the device generator matches them to 2e-13).  Heavy tails make a few closed loops amplify
@@ -619,6 +621,7 @@ def test_full_size_config2_product_noise_all_299_steps(uvs):
     from oracle import c_oracle
     T, K = 65536, 299
     cfg = bench.config2()
+    cfg['estimator']['method'] = method
     res = uvs.batch.run_batch(cfg, cells=[1.5], want=('err', 'q'))
     assert res.stats.shape == (T, 3) and len(res.plan) == T and int(res.plan.seed[0]) == 123456
     sample = np.unique(np.concatenate([np.arange(0, T, 128), [0, 1, 31, 32, 63, 64, 1000, 4097, 8191, 12345, 16384, 20000, 30001, 32767, 32768, 40000, 44444, 50000, 54321, 60000, 65000, 65503, 65534, 65535]]))
@@ -626,16 +629,18 @@ def test_full_size_config2_product_noise_all_299_steps(uvs):
     for i, t in enumerate(sample):
         uvs.batch.trial_noise(cfg, res.plan, int(t), int(t) + 1, K, noise[i:i + 1])
     des = cfg['experiments']['desired_f']
-    ref = c_oracle.closed_loop_batch(res.plan.q_start[sample], noise, des)
-    ref2 = c_oracle.closed_loop_batch(res.plan.q_start[sample] * (1.0 + 1e-14), noise, des)
+    ref = c_oracle.closed_loop_batch(res.plan.q_start[sample], noise, des, method=method)
+    ref2 = c_oracle.closed_loop_batch(res.plan.q_start[sample] * (1.0 + 1e-14), noise, des, method=method)
     status, k_done = res.status.cpu().numpy(), res.k_done.cpu().numpy()
     err, q, stats = res.streams['err'], res.streams['q'], res.stats.cpu().numpy()
     calm = 0
     for i, t in enumerate(sample):
-        assert int(ref['status'][i]) == int(status[t]) and int(ref['k_done'][i]) == int(k_done[t]), int(t)
-        kd = int(k_done[t])
+        same_verdict = int(ref['status'][i]) == int(ref2['status'][i]) and int(ref['k_done'][i]) == int(ref2['k_done'][i])
+        if same_verdict:                                                     # (an MCKF trial near its subnormal-weight FAIL can end at another step
+            assert int(ref['status'][i]) == int(status[t]) and int(ref['k_done'][i]) == int(k_done[t]), int(t)   # in the oracle's own re-run)
+        kd = min(int(k_done[t]), int(ref['k_done'][i]), int(ref2['k_done'][i]))
         sens = max(rel_err(ref2['err'][i, :kd], ref['err'][i, :kd]), rel_err(ref2['q'][i, :kd], ref['q'][i, :kd]))
-        if sens > 1e-11:
+        if sens > 1e-11 or not same_verdict:
             continue                                                         # the oracle does not reproduce itself here: not a parity statement
         calm += 1
         assert rel_err(err[:kd, :, int(t)].cpu().numpy(), ref['err'][i, :kd]) <= 1e-8, int(t)
@@ -643,8 +648,9 @@ def test_full_size_config2_product_noise_all_299_steps(uvs):
         if status[t] == 0:
             assert np.abs(stats[t] - ref['stats'][i]).max() / ref['stats'][i].max() <= 1e-8, int(t)
     assert len(sample) >= 530 and calm >= 0.7 * len(sample), (calm, len(sample))
-    # the launch that bench.py times is this one: same failed-trial count as the bench line reports for the headline
-    assert int((status != 0).sum()) < T // 1000
+    # the launch that bench.py times is this one: same failed-trial count as the bench line reports (headline 0; MCKF 581: the reference's
+    # subnormal-weight path)
+    assert int((status != 0).sum()) <= max_failed
 
 
 def test_full_size_config3_properties(uvs):
