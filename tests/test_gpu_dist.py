@@ -35,10 +35,11 @@ def _env():
     return env
 
 
-def _run_ranks(world, total, backend, out_dir):
+def _run_ranks(world, total, backend, out_dir, sweep=False):
     for attempt in range(3):                                                  # a port found free can be taken before the ranks bind it: try another
         port = _free_port()
-        procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(total), backend, str(out_dir)], env=_env(), cwd=ROOT,
+        env = dict(_env(), UVS_TEST_SWEEP='1') if sweep else _env()
+        procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(total), backend, str(out_dir)], env=env, cwd=ROOT,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
         logs = []
         for p in procs:
@@ -92,6 +93,20 @@ def test_sharded_sweep_on_the_hip_kernel_equals_one_rank(tmp_path, world, total)
         assert np.array_equal(z['rows'], single), f'rank {r}: gathered rows differ from the one-rank sweep'
         assert np.array_equal(z['k_done'], k_single[lo:hi])
     assert sum(int(z['hi']) - int(z['lo']) for z in parts) == total
+
+
+@pytest.mark.timeout(900)
+def test_sharded_run_sweep_and_gather_equal_one_rank(tmp_path):
+    """batch.run_sweep on 3 gloo ranks sharing the GPU (ragged shards, pieces of 64 trials) + SweepResult.gather: every rank ends up with
+    the one-rank table, k_done included."""
+    import uvs_amd
+    total = 301
+    parts = _run_ranks(3, total, 'gloo', tmp_path, sweep=True)
+    single, k_single = _single_rank(total)
+    for r, z in enumerate(parts):
+        lo, hi = uvs_amd.dist.shard_range(total, r, 3)
+        assert (int(z['lo']), int(z['hi'])) == (lo, hi)
+        assert np.array_equal(z['rows'], single) and np.array_equal(z['k_done_all'], k_single) and np.array_equal(z['k_done'], k_single[lo:hi])
 
 
 @pytest.mark.timeout(900)

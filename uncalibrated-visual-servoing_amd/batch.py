@@ -216,6 +216,15 @@ class SweepResult:
         from . import stats as _stats
         return _stats.cell_summary(self.stats, self.status, self.plan.cell[self.lo:self.hi])
 
+    def gather(self, group=None, device=None):
+        """The rows of ALL ranks in global trial order, (len(plan), 5), on every rank: the sweep's one collective, an all-gather
+        of 40 B per trial.  ``device``: where the exchanged tensors live -- a cuda device for the nccl (RCCL) backend, None (host) for gloo."""
+        import torch
+        rows = torch.from_numpy(np.ascontiguousarray(self.rows()))
+        if device is not None:
+            rows = rows.to(device)
+        return dist.gather_trial_rows(rows, len(self.plan), group).cpu().numpy()
+
 
 def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(), lanes=0, device='cuda', max_trials=None,
               share_noise=True, on_piece=None, strict_pinv=False, latency=False, plan=None):
