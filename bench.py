@@ -342,6 +342,49 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4        # 256 CUs x 4 SIMDs, one wa
 FP64_VECTOR_PEAK_FLOPS = 78.6e12                     # MI355X_MICROARCH.md: fp64 vector peak
 
 
+def drop_in_step_latency(torch, uvs_amd, engine, dev, steps=400, warm=50):
+    """Latency of the drop-in STEP route (side object): what Experiment.run() pays per loop iteration for the estimator + control law when the
+    robot is external (uncalibrated-visual-servoing_amd/experiment.py `_run_with_external_robot`, replacing experiment.py:166-312 of the
+    reference, which measured 260-430 us per update on the build container's CPU).  Host clock around
+    FilterBank.step_host -- numpy f / f_old in, numpy dq / err / status out, synchronised -- for T = 1 (the drop-in) and T = 64, and around the
+    round-5 route it replaces (three H2D tensors, launch, .item() + two .cpu() reads)."""
+    cfg = config2()
+    des = cfg['experiments']['desired_f']
+    out = {}
+    rng = np.random.default_rng(7)
+    for T in (1, 64):
+        fp = engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, des, True, 0, 0)
+        x0 = rng.normal(size=(T, 48)) * 50
+        f = np.asarray(des)[None] + rng.normal(size=(T, 8))
+        for route in ('host_io', 'tensors'):
+            bank = engine.FilterBank(fp, T, x0, dev)
+            dq = np.zeros((T, 6))
+            lap = []
+            for k in range(warm + steps):
+                f_old, f = f, f + 0.1 * rng.normal(size=(T, 8))
+                t0 = time.perf_counter()
+                if route == 'host_io':
+                    dq_h, err_h, _, st = bank.step_host(f, f_old, k % 299, dq)
+                    bad = int(st[0])
+                    dq = dq_h.copy()
+                else:
+                    to = lambda a: torch.as_tensor(a, device=dev)          # noqa: E731
+                    dq_t, err_t, _, st = bank.step(to(f), to(f_old), to(dq), k % 299)
+                    bad = int(st[0].item())
+                    dq = dq_t.cpu().numpy()
+                    err_h = err_t.cpu().numpy()
+                lap.append(time.perf_counter() - t0)
+                assert bad == 0
+            lap = np.array(lap[warm:]) * 1e6
+            out[f'T{T}_{route}'] = {'median_us': float(np.median(lap)), 'mean_us': float(lap.mean()), 'p95_us': float(np.quantile(lap, 0.95))}
+    out['step_latency_us'] = {'T1': out['T1_host_io']['median_us'], 'T64': out['T64_host_io']['median_us']}
+    out['reference_us_per_update'] = [260, 430]
+    out['note'] = ('host wall clock per Experiment-loop iteration of the estimator + control-law step, inputs and outputs as numpy arrays on the host; host_io = '
+                   'FilterBank.step_host (pinned zero-copy records, one launch + one stream synchronisation), tensors = the round-5 route; reference figure: '
+                   'BASELINE.md section 2 (numpy, build container)')
+    return out
+
+
 def parse_rocm_smi(text):
     """(package watts, shader clock in MHz, power cap in watts) from `rocm-smi --showpower --showclocks --showmaxpower` text; None where absent."""
     import re
@@ -865,10 +908,29 @@ def main():
                         ms.append(e0.elapsed_time(e1))
                 upd = int(k_done.sum().item())
                 avg = float(np.mean(ms))
+                rec_ms = None
+                if meth in ('KF', 'IMCCKF') and args.layout == 'kct' and T % 16 == 0:
+                    # what shipped in round 5 for these two: X written as per-trial records ([step][trial][component], engine.closed_loop(x_layout='ktc')),
+                    # the narrow streams unchanged -- the same buffer viewed as records, same bits
+                    x_rec = (bufs['x']._base if bufs['x']._base is not None else bufs['x']).reshape(-1)[:K * T * M * N].view(K, T, M * N)
+                    rms = []
+                    for i in range(2 + 5):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        uvs_amd._lib.check(engine.launch_closed_loop(fp, plant, T, flat(q0), engine.stream_view(noise, 'kct'), NV, engine.stream_view(x_rec, 'ktc'),
+                                                                     engine.stream_view(bufs['err'], 'kct'), engine.stream_view(bufs['q'], 'kct'), NV, NV, stats.data_ptr(),
+                                                                     status.data_ptr(), k_done.data_ptr(), NV, NV, device=dev))
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if i >= 2:
+                            rms.append(e0.elapsed_time(e1))
+                    rec_ms = float(np.mean(rms))
                 others[key] = {'avg_kernel_ms': avg, 'updates_per_s': upd / (avg * 1e-3), 'achieved': upd * b_alg / (avg * 1e-3) / 1e9, 'unit': 'GB/s',
                                'frac': upd * b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches_timed': 5, 'alpha': alpha, 'updates_per_launch': upd,
                                'failed_trials': int((status != 0).sum().item()),
                                'work_items_per_trial': int(uvs_amd.lib().uvs_rmckf_closed_loop_segments(C.byref(fp), C.byref(plant), T))}
+                if rec_ms is not None:
+                    others[key]['x_records'] = {'avg_kernel_ms': rec_ms, 'frac': upd * b_alg / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'x_layout': 'ktc'}
                 noise = noise_head
             fp = fp_head
         shard_model = None
@@ -937,6 +999,7 @@ def main():
                 bufs[key] = None                                   # 9.7 GB of config-2 streams: make room for 44 GB (config 3) / 41 GB (config 5)
             del noise
             torch.cuda.empty_cache()
+            side['drop_in'] = drop_in_step_latency(torch, uvs_amd, engine, dev)
             if not args.no_e2e:
                 side['e2e'] = e2e_sweep(torch, uvs_amd, engine, batch, dev)
             if not args.e2e:
@@ -970,7 +1033,7 @@ def main():
                           'strong_series': strong_side, 'shard_model': shard_model},
             'cpu_baseline': cpu,
             'replay': replay,
-            'config3': side.get('config3'), 'config3_hold': side.get('config3_hold'), 'config5': side.get('config5'), 'other_estimators': others, 'e2e': side.get('e2e'),
+            'config3': side.get('config3'), 'config3_hold': side.get('config3_hold'), 'config5': side.get('config5'), 'other_estimators': others, 'e2e': side.get('e2e'), 'drop_in': side.get('drop_in'),
             'setup': {'noise': 'host numpy' if args.host_noise else 'device (uvs_noise_generate_f64)', 'noise_gen_s': gen_s,
                       'noise_gen_workers': workers if args.host_noise else 0, 'h2d_s': h2d_s,
                       'h2d_inclusive_updates_per_s': total_updates / (wall / args.steps + h2d_s) if (world == 1 and args.host_noise) else None},

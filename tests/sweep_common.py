@@ -1,0 +1,99 @@
+"""Shared by tests/test_sweep_golden.py (CPU) and tests/test_gpu_sweep.py: the reference's EXPERIMENT fixtures (tests/golden/sweep_*.npz, written
+by oracle/gen_golden_sweep.py from the results.csv of the unmodified main.py) against a candidate -- the C oracle or batch.run_sweep.
+
+A heavy-tailed closed loop can amplify rounding (Cauchy noise, the MCKF / IMCC-KF cells near alpha = 1): whether a trial is a
+parity statement at all is decided by the ORACLE ALONE -- it must reproduce itself (status, k_done, statistics to 1e-9) from a start moved by
+1e-14.  The oracle re-run is made only for trials where the candidate deviates, which is what keeps the CPU suite short."""
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+SWEEPS = sorted(os.path.basename(p)[len('sweep_'):-4] for p in __import__('glob').glob(os.path.join(GOLDEN, 'sweep_*.npz')))
+K = 299
+STATS_TOL = 1e-8          # stats <= 1e-9 is the oracle-vs-kernel gate on calm trials; 1e-8 is the verdict's bar against the reference
+MEDIAN_TOL = 1e-6
+
+
+def load_sweep(name):
+    z = np.load(os.path.join(GOLDEN, f'sweep_{name}.npz'))
+    d = {k: z[k] for k in z.files}
+    d['config'] = json.loads(str(d['config']))
+    d['config'].pop('_provenance', None)
+    return d
+
+
+def oracle_kwargs(cfg):
+    p = cfg['estimator']['estimator_params']
+    ex = cfg['experiments']
+    return dict(method=cfg['estimator']['method'], kernel_bw=p['kernel_bw'], annealing=p['annealing'], dt=ex['dt'], t_max=ex['t_max'],
+                gain=ex['ibvs_gain'], fpi_threshold=p['fpi_threshold'], fpi_epoch_max=p['fpi_epoch_max'])
+
+
+def host_noise(uvs, cfg, plan, idx=None):
+    idx = np.arange(len(plan)) if idx is None else np.asarray(idx)
+    noise = np.zeros((len(idx), K, len(cfg['experiments']['desired_f'])))
+    if len(idx) == len(plan):
+        uvs.batch.trial_noise(cfg, plan, 0, len(plan), K, noise)
+    else:
+        for i, t in enumerate(idx):
+            uvs.batch.trial_noise(cfg, plan, int(t), int(t) + 1, K, noise[i:i + 1])
+    return noise
+
+
+def deviation(stats, status, k_done, ref):
+    """Per trial: relative deviation of the three norms, and whether status and k_done agree."""
+    dev = np.abs(stats - ref['stats']).max(axis=1) / np.abs(ref['stats']).max(axis=1)
+    return dev, (status == ref['status']) & (k_done == ref['k_done'])
+
+
+def calm_mask(uvs, cfg, plan, suspects):
+    """Which of the trials ``suspects`` the oracle reproduces from a start moved by 1e-14 (True = calm, a parity statement)."""
+    from oracle import c_oracle
+    if len(suspects) == 0:
+        return np.zeros(0, bool)
+    noise = host_noise(uvs, cfg, plan, suspects)
+    des, kw = cfg['experiments']['desired_f'], oracle_kwargs(cfg)
+    a = c_oracle.closed_loop_batch(plan.q_start[suspects], noise, des, **kw)
+    b = c_oracle.closed_loop_batch(plan.q_start[suspects] * (1.0 + 1e-14), noise, des, **kw)
+    same = (a['status'] == b['status']) & (a['k_done'] == b['k_done'])
+    sens = np.abs(a['stats'] - b['stats']).max(axis=1) / np.abs(a['stats']).max(axis=1)
+    return same & (sens <= 1e-9)
+
+
+def check_against_reference(uvs, name, ref, plan, stats, status, k_done, who):
+    """The gates of VERDICT r5 #1.  Returns the summary line (also printed: pytest -s / the GPUTEST tail show it)."""
+    cfg = ref['config']
+    T = len(plan)
+    assert T == len(ref['status']) == 1200 and np.array_equal(plan.q_start, ref['q_first'])      # main.py:129-134: jitter draws, bit for bit
+    assert np.allclose(plan.value, ref['rho'], rtol=0, atol=1e-15)
+    dev, verdict = deviation(stats, status, k_done, ref)
+    suspects = np.nonzero(~verdict | ~(dev <= STATS_TOL))[0]
+    calm = np.ones(T, bool)
+    calm[suspects] = calm_mask(uvs, cfg, plan, suspects)
+    # every trial the oracle reproduces: status / k_done exact, statistics to 1e-8
+    bad = np.nonzero(calm & (~verdict | ~(dev <= STATS_TOL)))[0]
+    assert len(bad) == 0, (name, who, bad[:10], dev[bad[:10]])
+    cell = plan.cell
+    fails_ref = np.array([int(ref['status'][cell == c].sum()) for c in range(12)])
+    fails_me = np.array([int(status[cell == c].sum()) for c in range(12)])
+    chaotic = np.array([int((~calm)[cell == c].sum()) for c in range(12)])
+    assert np.array_equal(fails_ref, ref['cell_n_fail']) and np.all(np.abs(fails_me - fails_ref) <= chaotic), (name, fails_ref, fails_me, chaotic)
+    assert np.array_equal([int(status[(cell == c) & calm].sum()) for c in range(12)], [int(ref['status'][(cell == c) & calm].sum()) for c in range(12)])
+    # per-cell median ITAE over the SUCCESS trials (plot_errorbar.m:25, 96): over the calm ones in cells where some trial is not
+    for c in range(12):
+        sel = (cell == c) & calm & (ref['status'] == 0)
+        if sel.sum():
+            mr, mm = np.median(ref['stats'][sel, 2]), np.median(stats[sel, 2])
+            assert abs(mm - mr) <= MEDIAN_TOL * mr, (name, c, mr, mm)
+        if chaotic[c] == 0 and ref['cell_n_success'][c]:
+            ok = (cell == c) & (status == 0)
+            for j in range(3):
+                assert abs(np.median(stats[ok, j]) - ref['cell_median'][c, j]) <= MEDIAN_TOL * ref['cell_median'][c, j]
+                assert abs(np.mean(stats[ok, j]) - ref['cell_mean'][c, j]) <= MEDIAN_TOL * ref['cell_mean'][c, j]
+    line = (f'sweep {name} ({who}): {T} trials of the reference main.py, FAIL ref {int(ref["status"].sum())} / here {int(status.sum())}, '
+            f'calm {int(calm.sum())} ({calm.mean():.3f}), statistics on calm trials max {dev[calm].max():.1e}, FAIL per cell ref {fails_ref.tolist()}')
+    print(line)
+    return line, calm

@@ -11,4 +11,4 @@ from .noise import NoiseProfiler, NoiseType, noise_batch  # noqa: F401
 from .plant import LinearPlant, SyntheticPlant, SyntheticRobot  # noqa: F401
 from .utils import gaussianKernel  # noqa: F401
 
-__version__ = '0.1.0'
+__version__ = "0.6.0"

@@ -23,48 +23,55 @@
 
 namespace uvs {
 
-// Diagnostic build -DUVS_STORES_INPLACE: every step overwrites the rows of step 0/1 (same instructions, traffic stays in L2).
-#ifdef UVS_STORES_INPLACE
-#define UVS_SK(sk) ((k & 1) ? -(sk) : (sk))
-#else
-#define UVS_SK(sk) (sk)
-#endif
-
-// Diagnostic build -DUVS_STAMPS: per-phase cycle sums (s_memtime) of every wavefront, written over the first words of that
-// wavefront's slice of `stats` (which is therefore garbage in this build).  Never used in the shipped library.
+// ---- Diagnostic builds (`make stamps`, `make quick QDEF=-DUVS_...`; into tools/diag/, never the shipped library).  One switch each; the
+// kernel below reads them with `if constexpr`, so a build without them contains none of this code.  Each writes its clock sums over the first
+// words of a wavefront's / segment's slice of `stats` (garbage in that build) and is read with tools/read_stamps.py / tools/wave_times.py:
+//   UVS_STAMPS       per-phase cycle sums (s_memtime) of the step loop            UVS_FPI_STAMPS   cycles of the MCKF fixed-point branch by phase
+//   UVS_ITEM_STAMPS  where a work item's time goes (entry / state / steps / hand-over, 100 MHz clock)
+//   UVS_WAVE_TIMES   when and where every wavefront ran (100 MHz clock, HW_ID, XCC_ID)
 #ifdef UVS_STAMPS
-#define UVS_STAMP(slot)                                                                   \
-    do {                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        unsigned long long now_;                                                          \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        stamp_sum[slot] += now_ - stamp_last;                                             \
-        stamp_last = now_;                                                                \
-    } while (0)
-#elif defined(UVS_PHASE_FENCE)
-// Keep the scheduler from interleaving instructions across phase boundaries: with a register file this full, cross-phase
-// hoisting lengthens live ranges into spills (measured on L = 4: 4.6 ms -> 3.6 ms).
-#define UVS_STAMP(slot) __builtin_amdgcn_sched_barrier(0)
+constexpr bool kDiagStamps = true;
 #else
-#define UVS_STAMP(slot) do { } while (0)
+constexpr bool kDiagStamps = false;
+#endif
+#ifdef UVS_FPI_STAMPS
+constexpr bool kDiagFpi = true;
+#else
+constexpr bool kDiagFpi = false;
+#endif
+#ifdef UVS_ITEM_STAMPS
+constexpr bool kDiagItems = true;
+#else
+constexpr bool kDiagItems = false;
+#endif
+#ifdef UVS_WAVE_TIMES
+constexpr bool kDiagWaves = true;
+#else
+constexpr bool kDiagWaves = false;
 #endif
 
-// Diagnostic build -DUVS_FPI_STAMPS: cycles of the MCKF fixed-point branch by phase (s_memtime sums per wavefront over the first words of its slice of
-// `stats`, which is garbage in this build; run with whole trials: tools/read_stamps.py --fpi).  Never in the shipped library.
-#ifdef UVS_FPI_STAMPS
-#define UVS_FPI_STAMP(slot)                                                               \
-    do {                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        unsigned long long now_;                                                          \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        if ((slot) >= 0) fpi_sum[(slot) < 0 ? 0 : (slot)] += now_ - fpi_last;             \
-        fpi_last = now_;                                                                  \
-    } while (0)
-#else
-#define UVS_FPI_STAMP(slot) do { } while (0)
-#endif
+UVS_DEV unsigned long long diag_cycles() {                       // shader clock
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+UVS_DEV unsigned long long diag_ticks() {                        // constant 100 MHz clock, one for the whole device
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+struct DiagPhases {                                              // sums of cycles between consecutive stamps, by slot
+    unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    UVS_DEV void stamp(int slot) {                               // slot < 0: restart the interval without booking it
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = diag_cycles();
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot >= 0) sum[slot] += now - last;
+        last = now;
+    }
+};
+#define UVS_STAMP(slot) do { if constexpr (kDiagStamps) diag_steps.stamp(slot); } while (0)
+#define UVS_FPI_STAMP(slot) do { if constexpr (kDiagFpi) diag_fpi.stamp(slot); } while (0)
 
 // DPP quad_perm move of a double (two 32-bit moves).  CTRL = a | b<<2 | c<<4 | d<<6 selects the source lane of each lane of a quad.
 template <int CTRL>
@@ -370,10 +377,6 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         for (int j = 0; j < N; ++j) pred = fma(x[j], dq[j], pred);
         nu = zi - pred;                                          // innovation (experiment.py:274)
     }
-#ifdef UVS_ABLATE_ROWS
-#pragma unroll
-    for (int l = 0; l < N; ++l) g[l] = pb[Sym<N>::at(l, l)] * dq[l];
-#else
 #pragma unroll
     for (int l = 0; l < N; ++l) pb[Sym<N>::at(l, l)] += 1.0;     // P + Q (experiment.py:167)
 #pragma unroll
@@ -385,18 +388,13 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         if (l == 1) row_hook<1>(hook);
         if (l == 3) row_hook<2>(hook);
     }
-#endif
     row_hook<3>(hook);
     double a = 0.0;
 #pragma unroll
     for (int l = 0; l < N; ++l) a = fma(dq[l], g[l], a);
     double gamma;
     if constexpr (METHOD == UVS_METHOD_GMCKF) {
-#ifdef UVS_ABLATE_EXP
-        kap = fast_rcp(fma(nu * nu, -neg_half_inv_s2, 1.0));
-#else
         kap = exp_nonpos((nu * nu) * neg_half_inv_s2);           // utils.py:171-172
-#endif
         const double d = kap + reg;                              // gamma = 1 / (a + 1/d) = d / (a d + 1) (experiment.py:280-286)
         gamma = d * fast_rcp(fma(a, d, 1.0));
     } else if constexpr (METHOD == UVS_METHOD_MCKF) {
@@ -442,7 +440,6 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         chk = fma(x[j], 0.0, chk);
     }
     row_hook<5>(hook);
-#ifndef UVS_ABLATE_ROWS
 #pragma unroll
     for (int l = 0; l < N; ++l) {                                // Joseph update with R = 1: P -= beta g g^T
         const double w = beta * g[l];
@@ -450,9 +447,6 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
         for (int j = l; j < N; ++j) pb[Sym<N>::at(l, j)] = fma(-w, g[j], pb[Sym<N>::at(l, j)]);
         if (l == 1) row_hook<6>(hook);
     }
-#else
-    pb[0] = fma(-beta, g[0], pb[0]);
-#endif
 }
 
 template <int N, int METHOD, typename Hook>
@@ -536,9 +530,7 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
             a[m][j] = fma(-d, vm, a[m][j]);
             // row c of R is final on its owner lane (the partner holds a row that is finished already, or one whose entries its column's
             // norm bounds): the running largest |R_cj|, one v_max_f64 with |.| modifiers per entry (see Spread::add_largest)
-#ifndef UVS_NO_ENTRY_WATCH             // experiment builds: A/B of the watch's cost
             if (j < N) rmax = fmax(rmax, fabs(a[m][j]));
-#endif
 #pragma unroll
             for (int r = m + 1; r < R; ++r) a[r][j] = fma(-d, a[r][c], a[r][j]);
         }
@@ -671,9 +663,7 @@ UVS_DEV bool lstsq_tall_emu2(double (&a)[2][N + 1], int sub, double (&sol)[N], b
                 a[0][j] = (rm == 0) ? (high ? u0 : a[0][j]) : a[0][j];
                 a[1][j] = high ? u1 : a[1][j];
             }
-#ifndef UVS_NO_ENTRY_WATCH
             if (j < N) { if (hm == 0) rmax_lo = fmax(rmax_lo, fabs(a[rm][j])); else rmax_hi = fmax(rmax_hi, fabs(a[rm][j])); }
-#endif
         }
         rdiag[c] = -copysign(rn, piv);
     }
@@ -726,25 +716,13 @@ struct PlantLds {
 // With L = 4 the whole state fits the 256 VALU-addressable registers (P: 84, X: 24), LDS holds only the statistics and
 // the plant constants, and two wavefronts share a SIMD (XREG = true, __launch_bounds__(64, 2)): measured 1.36x the fp64
 // issue rate of a lone wavefront, with scalar/LDS/memory instructions of one wavefront hidden under the other's arithmetic.
-#ifdef UVS_PERSISTENT
-__device__ unsigned g_uvs_work_counter;                  // experiment build only: next work item of the persistent grid (reset by the launcher)
-#endif
-#ifndef UVS_INC_SINCOS                  // experiment builds: 0 = sincos of every joint angle from scratch every step (round-2 code)
-#define UVS_INC_SINCOS 1
-#endif
-#ifndef UVS_FAIR_PRIO                   // log2 of the priority turn in shader clocks for the two-wavefront-per-SIMD kernels; experiment builds: 0 = off
-#define UVS_FAIR_PRIO 18
-#endif
+constexpr int kFairPrioLog2 = 18;       // log2 of the priority turn in shader clocks for the two-wavefront-per-SIMD kernels (12 / 15 / 18 measured, appendix A.2)
 // Wavefronts per SIMD the four-lane kernels are compiled for.  Round 3 shipped 2 (256 registers: the RMCKF instantiation then carried 36-68 B of
 // scratch inside the step loop); at 1 it takes 270 registers, no scratch, and is faster at every size measured (profiles/r04/shard_times.txt:
 // 8 192 trials 0.97 -> 0.90 ms, 16 384: 1.26 -> 1.00, 32 768: 2.06 -> 1.88).  Four lanes per filter are the LATENCY mapping (UVS_OPT_LATENCY):
 // half the trials per wavefront, 14 % fewer instructions per wavefront-step -- the shards of a strong-scaling series that do not fill the chip.
-#ifndef UVS_L4_OCC
-#define UVS_L4_OCC 1
-#endif
-#ifndef UVS_SHARED_OCC                  // experiment builds: wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
-#define UVS_SHARED_OCC 2
-#endif
+constexpr int kL4Occ = 1;
+constexpr int kSharedOcc = 2;           // wavefronts per SIMD of the two-lane KF / IMCC-KF kernels (one covariance block per lane)
 // SEGMENTED: the instantiation can run a trial chunk as several work items (see SEG below).  Always for MCKF, whose wavefronts differ in length;
 // for RMCKF a second instantiation that the launcher picks only when a launch is not a whole number of rounds of wavefronts (the code costs the
 // headline kernel 4 registers and 0.4 %, so the headline launch keeps the instantiation without it).
@@ -753,15 +731,11 @@ __device__ unsigned g_uvs_work_counter;                  // experiment build onl
 // over 48 rows of the trial-fastest layout.  KF / IMCC-KF are bound by the CU's store path; the launcher picks this
 // instantiation when the caller's x_out view has that shape.
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false>
-__global__ __launch_bounds__(64, (L >= 4 ? UVS_L4_OCC : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? UVS_SHARED_OCC : 1))
+__global__ __launch_bounds__(64, (L >= 4 ? kL4Occ : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? kSharedOcc : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     static_assert(!XREC || (XOUT && L == 2 && !EMU2 && M == 8 && N == 6 && METHOD != UVS_METHOD_MCKF), "record stores: the (8,6) two-lane kernels with X in LDS (MCKF rewrites rows of a step)");
-#ifdef UVS_L4_XLDS
-    constexpr bool XREG = false;
-#else
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
-#endif
     // MCKF trials differ in length (a trial that iterates costs its whole wavefront the fixed-point branch): with exactly two rounds of
     // wavefronts a slow one serialises with its slot's second wavefront.  The two-lane MCKF kernel can therefore run a chunk's K steps as
     // A.n_seg work items, the state crossing through HBM (uvs_rmckf_closed_loop_ws_f64); same arithmetic, bit-identical results.  The RMCKF
@@ -786,20 +760,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     __shared__ double lds_acc[3 * R][64];
     __shared__ double lds_p[(PL > 0 && !((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1)) ? PL * NP : 1][64];
     __shared__ double lds_c[PC::kCount];
-#ifdef UVS_LDS_PAD_KB                   // experiment builds: dead LDS that caps the wavefronts per CU (occupancy A/B of one and the same code)
-    __shared__ double lds_pad[UVS_LDS_PAD_KB * 128];
-    lds_pad[threadIdx.x] = 0.0;
-    asm volatile("" ::"v"(&lds_pad[threadIdx.x]) : "memory");
-#endif
 
-#ifdef UVS_WAVE_TIMES                   // diagnostic build: when and where did this wavefront run (100 MHz wall clock, HW_ID, XCC_ID)
-    unsigned long long wt_first;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
-#endif
-#ifdef UVS_ITEM_STAMPS                  // diagnostic build: where a work item's time goes (100 MHz wall clock): entry -> state ready -> steps done -> handed over;
-    unsigned long long it_t0, it_t1, it_t2, it_t3, it_ta = 0, it_tb = 0;   // summed per segment into the first words of `stats` (garbage there), tools/read_stamps.py --items
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t0)::"memory");
-#endif
+    // diagnostics (dead code unless a kDiag* switch is on): entry time of the wavefront / work item; entry -> state ready -> steps done -> handed over
+    unsigned long long wt_first = 0, it_t0 = 0, it_t1 = 0, it_t2 = 0, it_t3 = 0, it_ta = 0, it_tb = 0;
+    if constexpr (kDiagWaves) wt_first = diag_ticks();
+    if constexpr (kDiagItems) it_t0 = diag_ticks();
     const unsigned lane = threadIdx.x;
     const int sub = (L == 1) ? 0 : (int)(lane & (L - 1));
     const int grp = SPLIT ? (EMU2 ? (sub & 1) : (sub < G ? sub : G - 1)) : 0;   // with L = 4 the fourth lane mirrors group 2 (EMU2: group = parity)
@@ -812,38 +777,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int u = 0; u < L; ++u) cand[u] = at(r * RS + (EMU2 ? 4 * (u >> 1) + (u & 1) : u));
         return pick_sub<L>(cand, sub);
     };
-#ifdef UVS_PERSISTENT                   // experiment build: a persistent grid (as many wavefronts as the chip holds) pulling 64 / L-trial work
-    for (;;) {                          // items from a global atomic counter instead of one workgroup per item (measured, not shipped)
-        unsigned item_ = 0;
-        if (lane == 0) item_ = atomicAdd(&g_uvs_work_counter, 1u);
-        item_ = (unsigned)__builtin_amdgcn_readfirstlane((int)item_);
-        if ((long long)item_ * TPW >= A.T) break;
-        const long long wave_first = (long long)item_ * TPW;
-        const long long chunk = item_;
-        const int seg = 0;
-#ifdef UVS_WAVE_TIMES
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_first)::"memory");
-#endif
-#define UVS_ITEM_END continue
-#elif defined(UVS_WAVE_TIMES)           // experiment: workgroup -> trial-chunk mappings (bits 16-23 of A.fp.reserved select; 0 = identity)
-#define UVS_ITEM_END return
-    long long chunk = blockIdx.x;
-    int seg = 0;
-    if (SEG && A.n_seg > 1) {
-        const unsigned nchunks = gridDim.x / (unsigned)A.n_seg;
-        seg = (int)(blockIdx.x / nchunks);
-        chunk = blockIdx.x - (unsigned)seg * nchunks;
-    } else {
-        const int map_ = (A.fp.reserved >> 16) & 0xff;
-        const long long nw = gridDim.x, nfull = (nw / 8) * 8;
-        if (map_ == 1 && chunk < nfull) chunk = (chunk % 8) * (nfull / 8) + chunk / 8;      // XCD x owns a contiguous eighth of the trials
-        if (map_ >= 8 && map_ < 16 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (map_ - 8)) & 7);   // XCD x writes the 256-byte slot x + r of every 2 KB
-        if (map_ >= 16 && map_ < 24 && chunk < nfull) chunk = chunk ^ (map_ - 16);                             // ... slot x ^ r
-        if (map_ == 2 && chunk < nfull) chunk = (chunk & ~7ll) | ((chunk + (chunk >> 3)) & 7);                                    // ... every slot in turn
-    }
-    const long long wave_first = chunk * TPW;
-#else
-#define UVS_ITEM_END return
     // Work item = (trial chunk, segment).  Workgroups are dispatched in the order of their ids, so with ids laid out segment-major every
     // item's predecessor (same chunk, previous segment: an id smaller by the number of chunks) was dispatched before it and runs to its
     // end without waiting on anything later -- the hardware dispatcher is the work queue (MCKF).
@@ -857,7 +790,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
     }
     const long long wave_first = chunk * TPW;                      // first trial of this wavefront (uniform)
-#endif
     const unsigned tl = lane / L;                                   // trial within the wavefront
     const bool valid = wave_first + tl < A.T;
     const long long trial = valid ? wave_first + tl : A.T - 1;     // padding lanes shadow the last trial
@@ -1016,14 +948,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
     };
     await_predecessor();
-#ifdef UVS_ITEM_STAMPS
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_ta)::"memory");
-#endif
+    if constexpr (kDiagItems) it_ta = diag_ticks();
     if (!fresh) {
         seg_state(std::false_type{});
-#ifdef UVS_ITEM_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_tb)::"memory");
-#endif
+        if constexpr (kDiagItems) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); it_tb = diag_ticks(); }
     } else {
         double q_all[N];
 #pragma unroll
@@ -1103,23 +1031,36 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         pn += A.noise.sk;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): keep "nz_next may be in flight" out of the loop header (see rmckf_replay_tuned.hpp)
-#ifdef UVS_ITEM_STAMPS
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t1)::"memory");
-#endif
-
-#ifdef UVS_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
-    unsigned long long rt_first;                                 // constant 100 MHz counter: slot 4 = wall ticks of the loop -> shader clock
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
-#endif
+    if constexpr (kDiagItems) it_t1 = diag_ticks();
+    DiagPhases diag_steps, diag_fpi;
+    unsigned long long rt_first = 0, fpi_loop0 = 0;              // slot 4 of diag_steps = wall ticks of the loop (-> shader clock)
+    if constexpr (kDiagStamps) { diag_steps.last = diag_cycles(); rt_first = diag_ticks(); }
+    auto record_wave = [&]() {                                   // (kDiagWaves) this wavefront's interval and place into its slice of `stats`
+        if (lane == 0 && A.stats) {
+            unsigned hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            double *w_ = A.stats + 3 * wave_first + 4 * seg;
+            w_[0] = (double)wt_first; w_[1] = (double)diag_ticks(); w_[2] = (double)hw_id; w_[3] = (double)xcc_id;
+        }
+    };
+    auto record_item = [&](bool handed_over) {                   // (kDiagItems) sums per segment over the first words of `stats`
+        if (lane == 0 && A.stats) {
+            atomicAdd(&A.stats[8 * seg + 0], (double)(it_t1 - it_t0));
+            atomicAdd(&A.stats[8 * seg + 1], (double)(it_t2 - it_t1));
+            if (handed_over) atomicAdd(&A.stats[8 * seg + 2], (double)(it_t3 - it_t2));
+            atomicAdd(&A.stats[8 * seg + 3], 1.0);
+            atomicAdd(&A.stats[8 * seg + 4], (double)(it_ta - it_t0));
+            if (it_tb) atomicAdd(&A.stats[8 * seg + 5], (double)(it_tb - it_ta));
+        }
+    };
 
     // Two wavefronts per SIMD (KF, IMCC-KF): left alone, issue arbitration serves the older wavefront first -- it finishes its 299 steps in
     // 1.7 ms, the younger one in 2.4-2.8 ms, and runs the last third of its trial without a partner to hide its latencies behind.  The two
     // take turns at the higher priority instead, by the shader clock (a turn = 2^18 cycles = 125 us), told apart by the parity of their
     // wave slot; with equal parities both follow the same schedule and nothing changes.  Measured: residency 0.77 -> 0.86, KF 2.49 -> 2.43 ms.
     unsigned fair_slot = 0;
-    constexpr bool FAIR = SHARED_P && L == 2 && UVS_FAIR_PRIO > 0;
+    constexpr bool FAIR = SHARED_P && L == 2;
     if constexpr (FAIR) {
         unsigned hw_id_;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id_));
@@ -1149,10 +1090,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             }
         }
     };
-#ifdef UVS_FPI_STAMPS
-    unsigned long long fpi_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fpi_last = 0, fpi_loop0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fpi_loop0)::"memory");
-#endif
+    if constexpr (kDiagFpi) fpi_loop0 = diag_cycles();
     for (int k = k_begin; k < k_end; ++k) {
         asm volatile("" ::: "memory");                           // keep the LDS-resident constants out of loop-invariant hoisting
         // (XREC) the records of the PREVIOUS step leave now: their LDS reads and stores have the whole plant phase to drain under -- issued in one
@@ -1161,7 +1099,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         UVS_STAMP(5);
         if constexpr (FAIR) {
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();
-            if ((((unsigned)(now_ >> (UVS_FAIR_PRIO > 0 ? UVS_FAIR_PRIO : 1))) ^ fair_slot) & 1u) __builtin_amdgcn_s_setprio(3);
+            if ((((unsigned)(now_ >> kFairPrioLog2)) ^ fair_slot) & 1u) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
         }
         // ---- measurement noise: this step's values were requested a whole step ago; request the next step's now.  vmcnt counts in
@@ -1177,14 +1115,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         }
         // ---- plant: noise-free features of this lane's rows
         double z[R];
-#ifdef UVS_ABLATE_PLANT           // diagnostic build: cheap stand-in that keeps the dependence on q
-#pragma unroll
-        for (int r = 0; r < R; ++r) z[r] = fma(q[r % JG], 100.0, 128.0);
-        if constexpr (true) {
-        } else if constexpr (PLANT == UVS_PLANT_LINEAR) {
-#else
         if constexpr (PLANT == UVS_PLANT_LINEAR) {
-#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = r * RS + rb;
@@ -1200,7 +1131,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             const double *cj = &lds_c[PC::kJoint + 5 * JG * grp];
             // Whether a lane re-seeds, and from which routine, is decided per lane (the wavefront only shares the branch): a trial's
             // results do not depend on its neighbours in the batch.
-            const bool need = !UVS_INC_SINCOS || reseed || (k & (kSinCosResync - 1)) == 0;
+            const bool need = reseed || (k & (kSinCosResync - 1)) == 0;
             if (__any(need)) {
                 double th[JG], s_new[JG], c_new[JG];
                 bool big = false;
@@ -1354,10 +1285,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             }
         }
         UVS_STAMP(0);                                            // noise-load issue + plant
-#ifdef UVS_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slot 6: how long the oldest outstanding memory operation still takes
-        UVS_STAMP(6);
-#endif
+        if constexpr (kDiagStamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); UVS_STAMP(6); }   // slot 6: how long the oldest outstanding memory operation still takes
         const double sigma = bandwidth(fp, k);
         const double neg_half_inv_s2 = -0.5 * fast_rcp(sigma * sigma);
         double c_shared = 1.0;
@@ -1446,9 +1374,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 else lds_x[r * N + j][lane] = x[j];
             }
             if constexpr (XOUT && !XREC) {
-#ifdef UVS_ABLATE_STORES
-                if (k == K - 1)
-#endif
                 {
 #pragma unroll
                     for (int j = 0; j < N; ++j) px[(r * RS * N + j) * A.x_out.sc] = x[j];
@@ -1462,7 +1387,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
             }
         }
-        if constexpr (XOUT && !XREC) px += UVS_SK(A.x_out.sk);
+        if constexpr (XOUT && !XREC) px += A.x_out.sk;
         // LDS is the only copy of X from here on: forbid forwarding the stored values into the panel through registers
         asm volatile("" ::: "memory");
         UVS_STAMP(1);                                            // row updates (includes the wait for the noise load)
@@ -1502,9 +1427,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 const int own_off = EMU2 ? (g & 1) + 2 * (g >> 2) : (g & 1);      // ... and the owner's position in its lane group
                 unsigned long long todo = __ballot(more) & (EMU2 ? 0x1111111111111111ull : 0x5555555555555555ull);   // one bit per iterating filter: its first lane
                 UVS_FPI_STAMP(-1);
-#ifdef UVS_FPI_STAMPS
-                fpi_sum[6] += 1;
-#endif
+                if constexpr (kDiagFpi) diag_fpi.sum[6] += 1;
                 while (todo) {                                                    // rounds of up to 8 filters (uniform)
                     int src_even = -1, my_slot = -1;
 #pragma unroll
@@ -1717,19 +1640,11 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 panel[r][N] = kap[r] * err[r];
             }
             double sol[N];
-#ifdef UVS_ABLATE_QR
-#pragma unroll
-            for (int j = 0; j < N; ++j) sol[j] = pair_sum<L>(panel[j % R][j] * 1e-4 + panel[(j + 1) % R][N] * 1e-3);
-            chk = pair_sum<L>(chk);
-            bool nonfinite = !(chk == 0.0);
-            const bool suspect = false;
-#else
             // X non-finite: pinv would raise (experiment.py:313-316).  The verdict comes out of the QR's column norms (lstsq_tall_tuned);
             // the per-entry probe `chk` that the rows accumulate is dead code in this kernel.
             bool nonfinite, suspect;
             if constexpr (EMU2) suspect = lstsq_tall_emu2<M, N>(panel, sub, sol, nonfinite);
             else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite);
-#endif
             if constexpr (METHOD == UVS_METHOD_MCKF) nonfinite |= fpi.poison && !fpi.skip;      // the reference's NaN state after a subnormal weight
             if (alive && nonfinite) {
                 alive = false;
@@ -1747,7 +1662,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         if (on_err) {
 #pragma unroll
             for (int r = 0; r < R; ++r) pe[r * RS * A.err_out.sc] = err[r];
-            pe += UVS_SK(A.err_out.sk);
+            pe += A.err_out.sk;
         }
         if (on_f) {
 #pragma unroll
@@ -1764,7 +1679,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         if (on_q) {
 #pragma unroll
             for (int u = 0; u < JG; ++u) pq[u * A.q_out.sc] = q[u];
-            pq += UVS_SK(A.q_out.sk);
+            pq += A.q_out.sk;
         }
         if (on_dq) {
 #pragma unroll
@@ -1780,7 +1695,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             lds_acc[2 * R + r][lane] = fma(t, ae, acc_now[2 * R + r]);
         }
         UVS_STAMP(3);                                            // logs + statistics
-        if constexpr (UVS_INC_SINCOS && DH) {
+        if constexpr (DH) {
             if constexpr (kSinCosStepMax2 > kSinCosStepMax) {
                 // Two tiers, chosen PER LANE (the wavefront only shares the branch, so a trial's bits do not depend on its neighbours): steps up
                 // to 0.1 rad by the short polynomials, steps up to 1 rad by the long ones, anything else re-seeds from the angle at the next step.
@@ -1817,21 +1732,15 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
         for (int u = 0; u < JG; ++u) q[u] = fma(dq_own[u], fp.dt, q[u]);       // new_q = q + dq t_s (experiment.py:320)
         t += fp.dt;
     }
-#ifdef UVS_ITEM_STAMPS
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t2)::"memory");
-#endif
+    if constexpr (kDiagItems) it_t2 = diag_ticks();
     if constexpr (XREC) { if (k_end > k_begin) store_records(k_end - 1); }   // the last step's records (after a wavefront-wide FAIL: rows past every k_done, unspecified)
-#ifdef UVS_STAMPS
-    {
-        unsigned long long rt_last;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_last)::"memory");
-        stamp_sum[4] = rt_last - rt_first;
+    if constexpr (kDiagStamps) {
+        diag_steps.sum[4] = diag_ticks() - rt_first;
+        if (lane == 0 && A.stats) {
+            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)diag_steps.sum[c];
+        }
+        return;
     }
-    if (lane == 0 && A.stats) {
-        for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
-    }
-    return;
-#endif
 
     if constexpr (SEG) {
         if (!last_seg) {                                         // hand the chunk to its next segment: state, then the release of the counter
@@ -1849,52 +1758,19 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             if (lane == 0 && !((A.fp.reserved & UVS_OPT_DIAG_DROP_SEG_FLAG) && seg == 0))
                 __hip_atomic_store(&A.ws_flags[chunk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the counter moves
             }
-#ifdef UVS_WAVE_TIMES
-            if (lane == 0 && A.stats) {
-                unsigned long long wt_last;
-                unsigned hw_id, xcc_id;
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_last)::"memory");
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-                double *ws_ = A.stats + 3 * wave_first + 4 * seg;
-                ws_[0] = (double)wt_first; ws_[1] = (double)wt_last; ws_[2] = (double)hw_id; ws_[3] = (double)xcc_id;
-            }
-#endif
-#ifdef UVS_ITEM_STAMPS
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(it_t3)::"memory");
-            if (lane == 0 && A.stats) {
-                atomicAdd(&A.stats[8 * seg + 0], (double)(it_t1 - it_t0));
-                atomicAdd(&A.stats[8 * seg + 1], (double)(it_t2 - it_t1));
-                atomicAdd(&A.stats[8 * seg + 2], (double)(it_t3 - it_t2));
-                atomicAdd(&A.stats[8 * seg + 3], 1.0);
-                atomicAdd(&A.stats[8 * seg + 4], (double)(it_ta - it_t0));
-                if (it_tb) atomicAdd(&A.stats[8 * seg + 5], (double)(it_tb - it_ta));
-            }
-#endif
-            UVS_ITEM_END;
+            if constexpr (kDiagWaves) record_wave();
+            if constexpr (kDiagItems) { it_t3 = diag_ticks(); record_item(true); }
+            return;
         }
     }
-#ifdef UVS_ITEM_STAMPS
-    if (lane == 0 && A.stats) {                                  // the last segment (or a whole trial): no hand-over
-        atomicAdd(&A.stats[8 * seg + 0], (double)(it_t1 - it_t0));
-        atomicAdd(&A.stats[8 * seg + 1], (double)(it_t2 - it_t1));
-        atomicAdd(&A.stats[8 * seg + 3], 1.0);
-        atomicAdd(&A.stats[8 * seg + 4], (double)(it_ta - it_t0));
-        if (it_tb) atomicAdd(&A.stats[8 * seg + 5], (double)(it_tb - it_ta));
-    }
-    return;
-#endif
-#ifdef UVS_FPI_STAMPS
-    {
-        unsigned long long end_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(end_)::"memory");
-        fpi_sum[7] = end_ - fpi_loop0;                               // the whole step loop
+    if constexpr (kDiagItems) { record_item(false); return; }    // the last segment (or a whole trial): no hand-over
+    if constexpr (kDiagFpi) {
+        diag_fpi.sum[7] = diag_cycles() - fpi_loop0;             // the whole step loop
         if (lane == 0 && A.stats) {
-            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)fpi_sum[c];
+            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)diag_fpi.sum[c];
         }
         return;
     }
-#endif
     double s2[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1916,29 +1792,13 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) s2[c] = pair_sum<L>(s2[c]);
     }
-    if (!valid) UVS_ITEM_END;
+    if (!valid) return;
     if (sub == 0) {
-#ifdef UVS_WAVE_TIMES
-        if (A.stats && !(SEG && A.n_seg > 1)) {                 // (segmented: the chunk's slice of `stats` holds the stamps of every segment)
-#else
-        if (A.stats) {
-#endif
+        if (A.stats && !(kDiagWaves && SEG && A.n_seg > 1)) {   // (wave-times build, segmented: the chunk's slice of `stats` holds the stamps of every segment)
 #pragma unroll
             for (int c = 0; c < 3; ++c) A.stats[3 * trial + c] = sqrt(s2[c]);
         }
-#ifdef UVS_WAVE_TIMES
-        if (lane == 0 && A.stats) {                             // overwrites the statistics of the wavefront's first two trials
-            unsigned long long wt_last;
-            unsigned hw_id, xcc_id;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_last)::"memory");
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-            A.stats[3 * wave_first + 4 * seg + 0] = (double)wt_first;
-            A.stats[3 * wave_first + 4 * seg + 1] = (double)wt_last;
-            A.stats[3 * wave_first + 4 * seg + 2] = (double)hw_id;
-            A.stats[3 * wave_first + 4 * seg + 3] = (double)xcc_id;
-        }
-#endif
+        if constexpr (kDiagWaves) record_wave();                // overwrites the statistics of the wavefront's first two trials
         if (A.status) A.status[trial] = flagged ? UVS_STATUS_SUSPECT : status;
         if (A.k_done) A.k_done[trial] = k_done;
     }
@@ -1960,10 +1820,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                         SHARED_P ? p[0][Sym<N>::at(l, j)]
                                  : (r < PV) ? p[r < PV ? r : 0][Sym<N>::at(l, j)] : lds_p[(r >= PV ? r - PV : 0) * NP + Sym<N>::at(l, j)][lane];
     }
-#ifdef UVS_PERSISTENT
-    }                                   // next work item
-#endif
-#undef UVS_ITEM_END
 }
 
 }  // namespace uvs

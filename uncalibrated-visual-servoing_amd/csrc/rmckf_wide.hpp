@@ -21,14 +21,7 @@ namespace uvs {
 
 // Scheduling fence between the rows of a lane: without it the compiler interleaves the four row updates for instruction-level
 // parallelism, needs ~700 registers and spills to scratch; one wavefront per SIMD gains nothing from that interleaving anyway.
-#ifndef UVS_WIDE_OCC16
-#define UVS_WIDE_OCC16 1
-#endif
-#ifndef UVS_WIDE_NOFENCE
 #define UVS_WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define UVS_WIDE_FENCE() do { } while (0)
-#endif
 
 // v[idx] for a per-lane idx on a register-resident array (a select chain; a variably indexed access would go through scratch memory)
 template <int N>
@@ -120,7 +113,7 @@ UVS_DEV double wide_sum(double v) {
 // four lanes per filter -- 1 075 VALU instructions per wavefront-step against 1 109 (PMC): the replicated plant (~300) gives back what one row per
 // lane saves.  Reachable with lanes_per_filter = 8 (instead of the generic template); no launch policy selects it.
 template <int M, int N, int L, int METHOD, bool XOUT, bool XREC, int PLANT = UVS_PLANT_LINEAR>
-__global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loop_wide_kernel(const ClosedArgs A) {
+__global__ __launch_bounds__(64, 1) void closed_loop_wide_kernel(const ClosedArgs A) {
     static_assert(M % L == 0 && M >= N && (L == 8 || L == 16), "wide kernel: rows interleaved over 8 or 16 adjacent lanes (one DPP row)");
     constexpr int R = M / L, NP = Sym<N>::NP, TPW = 64 / L;
     constexpr bool DH = PLANT != UVS_PLANT_LINEAR;
@@ -233,12 +226,9 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         for (int u = 0; u < N; ++u) { sn[u] = 0.0; cs[u] = 1.0; }
     }
 
-#ifdef UVS_STAMPS                       // diagnostic build: per-phase cycle sums of every wavefront (tools/read_stamps.py --wide); `stats` is garbage then
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
-    unsigned long long rt_first;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_first)::"memory");
-#endif
+    DiagPhases diag_steps;                                         // -DUVS_STAMPS build: per-phase cycle sums of every wavefront (tools/read_stamps.py --wide); `stats` is garbage then
+    unsigned long long rt_first = 0;
+    if constexpr (kDiagStamps) { diag_steps.last = diag_cycles(); rt_first = diag_ticks(); }
     for (int k = 0; k < K; ++k) {
         UVS_STAMP(7);                                              // loop edge: joint integration, clock, (DH: sincos advance)
         double nz[R];
@@ -528,17 +518,13 @@ __global__ __launch_bounds__(64, (L >= 16 ? UVS_WIDE_OCC16 : 1)) void closed_loo
         t += fp.dt;
     }
 
-#ifdef UVS_STAMPS
-    {
-        unsigned long long rt_last;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_last)::"memory");
-        stamp_sum[4] = rt_last - rt_first;
+    if constexpr (kDiagStamps) {
+        diag_steps.sum[4] = diag_ticks() - rt_first;
         if (lane == 0 && A.stats) {
-            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)stamp_sum[c];
+            for (int c = 0; c < 8; ++c) A.stats[3 * wave_first + c] = (double)diag_steps.sum[c];
         }
         return;
     }
-#endif
     double s2[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -85,7 +85,10 @@ int small_batch_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64
 
 extern "C" {
 
-const char *uvs_version(void) { return "uvs_rmckf 0.1.0 (gfx950, fp64)"; }
+#ifndef UVS_SRC_HASH
+#define UVS_SRC_HASH "unknown"
+#endif
+const char *uvs_version(void) { return "uvs_rmckf 0.6.0 (gfx950, fp64) src:" UVS_SRC_HASH; }
 const char *uvs_last_error(void) { return g_err; }
 
 int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap) {

@@ -220,6 +220,48 @@ class FilterBank:
         self.kappa = torch.ones((T, m), dtype=torch.float64, device=device)
         self.status = torch.zeros(T, dtype=torch.int32, device=device)
         self.first = True
+        self._host = None
+
+    def _host_io(self):
+        """Pinned host records the step kernel reads and writes in place (zero-copy: hipHostMalloc memory is mapped into the device's address
+        space at the same address): two input records [f | f_old] and two output records [dq | err | kappa], status words, used alternately so
+        that call k reads the command of call k - 1 as its regressor.  numpy views are made once."""
+        torch = _torch()
+        m, n, T = self.fp.m, self.fp.n, self.T
+        pin = lambda *shape, dtype=torch.float64: torch.zeros(shape, dtype=dtype).pin_memory()      # noqa: E731
+        h = dict(f=pin(2, T, m), f_old=pin(2, T, m), dq=pin(2, T, n), err=pin(2, T, m), kappa=pin(2, T, m), status=pin(2, T, dtype=torch.int32))
+        h['np'] = {k_: v.numpy() for k_, v in h.items()}
+        ptr = {k_: [v[i].data_ptr() for i in (0, 1)] for k_, v in h.items() if k_ != 'np'}
+        fn = _lib.lib().uvs_rmckf_step_f64
+        fpref = C.byref(self.fp)
+        # everything of the call that does not change from step to step, per parity
+        h['call'] = [lambda first, k, dq_prev, stream, i=i: fn(fpref, self.T, self.X.data_ptr(), self.P.data_ptr(), ptr['f'][i], ptr['f_old'][i],
+                                                                dq_prev, first, k, ptr['dq'][i], ptr['err'][i], ptr['kappa'][i],
+                                                                ptr['status'][i], stream) for i in (0, 1)]
+        h['ptr'], h['calls'] = ptr, 0
+        return h
+
+    def step_host(self, f, f_old, k, dq_prev=None):
+        """The drop-in step for a caller whose data lives on the HOST (Experiment.run() with an external robot, experiment.py:166-312): ``f``,
+        ``f_old`` (T, m) array-likes; ``dq_prev`` (T, n) or None = the command the previous call returned (zero on the first).  No device copy
+        in either direction and no allocation: the kernel reads the inputs from and writes its outputs to pinned host memory; one launch, one
+        stream synchronisation.  Returns numpy views (dq (T, n), err (T, m), kappa (T, m), status (T,)) that stay valid until the next call
+        but one; X and P stay in HBM."""
+        h = self._host
+        if h is None:
+            h = self._host = self._host_io()
+        i = h['calls'] & 1
+        views = h['np']
+        views['f'][i][...] = f
+        views['f_old'][i][...] = f_old
+        if dq_prev is not None:
+            views['dq'][1 - i][...] = dq_prev
+        stream = _torch().cuda.current_stream()
+        _lib.check(h['call'][i](int(self.first), int(k), h['ptr']['dq'][1 - i], C.c_void_p(stream.cuda_stream)))
+        self.first = False
+        h['calls'] += 1
+        stream.synchronize()
+        return views['dq'][i], views['err'][i], views['kappa'][i], views['status'][i]
 
     def step(self, f, f_old, dq_prev, k):
         """f, f_old: (T, m), dq_prev: (T, n) cuda fp64 tensors.  Updates X, P in place; returns (dq, err, kappa, status)."""

@@ -166,17 +166,16 @@ class Experiment:
             except Exception as exc:
                 self.logger.error(exc)
             robot.computePose(recalculate_fkine=True)
-            to = lambda a: torch.as_tensor(np.asarray(a, float).reshape(1, -1), device=dev)   # noqa: E731
-            dq_t, err_t, _, st = bank.step(to(f), to(f_old), to(dq), k)
-            if int(st.item()) != 0:                                  # non-finite X: pinv would raise (experiment.py:313-316)
+            dq_h, err_h, _, st = bank.step_host(f, f_old, k, dq)    # zero-copy: inputs and outputs in pinned host memory, one launch
+            if st[0] != 0:                                           # non-finite X: pinv would raise (experiment.py:313-316)
                 status = ExperimentStatus.FAIL
                 self.logger.error('Experiment failed')
                 break
-            dq = dq_t[0].cpu().numpy()
+            dq = dq_h[0].copy()
             q_now = robot.getJointsPos()
             new_q = q_now + dq * self.t_s
             logs['q'][k], logs['cam'][k], logs['f'][k], logs['des'][k] = q_now, robot.computePose(), f, self.desired_f
-            logs['err'][k], logs['noise'][k], logs['t'][k] = err_t[0].cpu().numpy(), noise, t
+            logs['err'][k], logs['noise'][k], logs['t'][k] = err_h[0], noise, t
             k += 1
             robot.setJointsPos(new_q)
             robot.step()
