@@ -607,15 +607,15 @@ def test_full_size_batch_properties(uvs):
     assert int((full['status'] != 0).sum()) < T // 100
 
 
-@pytest.mark.parametrize('method,max_failed', [('GMCKF', 65), ('MCKF', 1000), ('KF', 65), ('IMCCKF', 65)])
-def test_full_size_config2_product_noise_all_299_steps(uvs, method, max_failed):
+@pytest.mark.parametrize('method,max_failed,min_calm', [('GMCKF', 65, 0.95), ('MCKF', 1000, 0.95), ('KF', 65, 0.95), ('IMCCKF', 65, 0.95)])
+def test_full_size_config2_product_noise_all_299_steps(uvs, method, max_failed, min_calm):
     """BASELINE config 2 exactly as bench.py runs it (VERDICT r3 #7a), and (round 5) the same launch for the other three estimators -- MCKF
     as the library's 8 tapered work items per trial at full size: 65 536 trials on the PRODUCT's alpha = 1.5 generator, global seeds
     123456 + t and jitter draws (main.py:121-139), noise through the shared T + 70-stream buffer (round 5).  536 trials spread over the grid
     (every 128th and the edges of wavefronts / rounds; round 4 sampled 24) are compared with oracle/c over ALL 299 steps on host noise of the
     same global indices (NoiseProfiler streams; the device generator matches them to 2e-13).  Heavy tails make a few closed loops amplify
     rounding: such trials are identified by the oracle itself, re-run from starts moved by 1e-14, and held to status /
-    k_done only; at least 70 % of the sample must be calm and within 1e-8."""
+    k_done only; the calm fraction is printed and gated per estimator at what was observed minus a small margin (``min_calm``)."""
     import torch
     import bench
     from oracle import c_oracle
@@ -647,7 +647,9 @@ def test_full_size_config2_product_noise_all_299_steps(uvs, method, max_failed):
         assert rel_err(q[:kd, :, int(t)].cpu().numpy(), ref['q'][i, :kd]) <= 1e-8, int(t)
         if status[t] == 0:
             assert np.abs(stats[t] - ref['stats'][i]).max() / ref['stats'][i].max() <= 1e-8, int(t)
-    assert len(sample) >= 530 and calm >= 0.7 * len(sample), (calm, len(sample))
+    print(f'full-size config 2, {method}: {calm} of {len(sample)} sampled trials calm ({calm / len(sample):.4f}) and within 1e-8 over all 299 steps; '
+          f'{int((status != 0).sum())} of {T} trials FAILed')                    # pytest -s / the GPUTEST tail; DESIGN.md section 2 quotes it
+    assert len(sample) >= 530 and calm >= min_calm * len(sample), (calm, len(sample))
     # the launch that bench.py times is this one: same failed-trial count as the bench line reports (headline 0; MCKF 581: the reference's
     # subnormal-weight path)
     assert int((status != 0).sum()) <= max_failed

@@ -166,3 +166,39 @@ def test_single_step_bank_uses_pinv_semantics(uvs):
         if k + 1 < 25:
             ref = g['dq_prev'][k + 1]
             assert np.abs(dq[0].cpu().numpy() - ref).max() <= 1e-8 * max(1e-3, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('lanes', (0, 16, -16))
+def test_wide_shape_closed_loop_on_a_kahan_like_jacobian(uvs, lanes):
+    """the (32,7) kernels solve the control law by the normal equations, whose Cholesky pivots -- like the |R_cc| of the QR
+    -- say nothing about a Kahan-like Jacobian (unit-diagonal triangle, every off-diagonal -1000, condition 1e19), and whose solution does not
+    even grow (squaring J has destroyed the small singular value).  Round 6 watches the REFINEMENT step instead: a correction of 2^-20 of the
+    solution marks the trial for the careful pass (tests/growth_watch_study.py --wide: <= 7e-14 healthy, >= 2e-3 or a broken factorisation on
+    Kahan-like steps).  Default mode, linear plant of BASELINE config 5, against the block oracle (numpy's pinv): the sick trial follows numpy's
+    truncated command (4e-4 at step 0; the plain normal-equation command is 0.27), its healthy neighbours in the batch stay within 1e-8."""
+    from oracle import rmckf_block
+    plant = uvs.LinearPlant.random(32, 7, seed=2)
+    rng = np.random.default_rng(77)
+    q_goal = plant.q0 + rng.uniform(-0.3, 0.3, 7)
+    des = plant.features(q_goal)
+    T, K, sick = 5, 40, 2
+    q0 = q_goal + rng.uniform(-0.15, 0.15, (T, 7))
+    noise = rng.standard_t(3, size=(T, K, 32)) * 0.5
+    x0 = np.tile((plant.J * (1 + 0.1 * rng.normal(size=plant.J.shape))).ravel(), (T, 1))
+    qq, _ = np.linalg.qr(rng.normal(size=(32, 7)))
+    kahan = 50.0 * qq @ (np.eye(7) - 1000.0 * np.triu(np.ones((7, 7)), 1))
+    x0[sick] = kahan.ravel()
+    y0 = plant.features(q0[sick]) - des
+    plain = np.linalg.solve(kahan.T @ kahan, kahan.T @ y0)
+    assert np.linalg.cond(kahan) > 1e18 and np.abs(plain).max() > 100 * np.abs(np.linalg.pinv(kahan) @ y0).max()      # the test has teeth
+    fp = uvs.engine.make_params(32, 7, 'GMCKF', 10.0, False, 0.05, 15, 0.2, des, False, lanes, steps=K)
+    out = uvs.engine.closed_loop(fp, plant.to_struct(), _cuda(q0), _cuda(noise.transpose(1, 2, 0)), _cuda(x0), want=('x', 'err', 'q', 'dq'))
+    assert not out['status'].cpu().numpy().any() and np.all(out['k_done'].cpu().numpy() == K)
+    for t in range(T):
+        ref = rmckf_block.run_closed_loop(plant.features, q0[t], des, noise[t], 0.05, 0.05 * (K + 0.5), 0.2, x0[t], method='GMCKF', initial_guess=False)
+        tol = 1e-6 if t == sick else 1e-8
+        assert rel_err(out['err'].cpu().numpy()[:, :, t], ref['err']) <= tol, t
+        assert rel_err(out['q'].cpu().numpy()[:, :, t], ref['q']) <= tol, t
+        assert rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']) <= tol, t
+    dq0 = out['dq'].cpu().numpy()[0, :, sick]
+    assert np.abs(dq0).max() < 1e-3                                        # numpy's truncated command, not the plain one (0.05)

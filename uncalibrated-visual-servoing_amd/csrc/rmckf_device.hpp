@@ -548,6 +548,7 @@ UVS_DEV void svd_solve(double (&A)[N][N], const double (&c)[N], double (&sol)[N]
 // grows with cond(J)^2 (one refinement step squares it again: measured against numpy's pinv 5e-14 relative at cond <= 1.5e3, the same
 // as Householder, 3e-11 at cond 1e5, 6e-9 at cond 1e6).
 constexpr unsigned kSuspectSpreadNormalEq = 40u << 20;
+constexpr unsigned kRefineGate = 20u << 20;      // refinement correction >= 2^-20 of the solution (high dwords): the normal equations have run out of digits
 
 // In place: G[at(j, i)], i > j, becomes L_ij; rs[j] = 1 / L_jj.  Returns the suspect verdict: pivots spread too far, or one of them
 // is not a positive normal number (zero / negative: breakdown; inf / NaN).

@@ -244,7 +244,7 @@ UVS_DEV void normal_eq_gram(const double (&x)[M][N], const double (&y)[M], doubl
 template <int M, int N>
 UVS_DEV bool normal_eq_finish(const double (&x)[M][N], const double (&y)[M], double (&G)[Sym<N>::NP], double (&b)[N], double (&sol)[N]) {
     double rs[N], c[N];
-    const bool suspect = chol_factor<N>(G, rs);
+    bool suspect = chol_factor<N>(G, rs);
     chol_solve_inplace<N>(G, rs, b);                             // s0
 #pragma unroll
     for (int j = 0; j < N; ++j) c[j] = 0.0;
@@ -257,6 +257,10 @@ UVS_DEV bool normal_eq_finish(const double (&x)[M][N], const double (&y)[M], dou
         for (int j = 0; j < N; ++j) c[j] = fma(x[i][j], ri, c[j]);
     }
     chol_solve_inplace<N>(G, rs, c);
+    double s_max = 0.0, c_max = 0.0;                             // refinement watch (rmckf_wide.hpp): a correction of 2^-20 of the solution marks the trial
+#pragma unroll
+    for (int j = 0; j < N; ++j) { s_max = fmax(s_max, fabs(b[j])); c_max = fmax(c_max, fabs(c[j])); }
+    suspect |= (unsigned)__double2hiint(c_max) + kRefineGate >= (unsigned)__double2hiint(s_max) && c_max > 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) sol[j] = b[j] + c[j];
     return suspect;

@@ -456,7 +456,6 @@ __global__ __launch_bounds__(64, 1) void closed_loop_wide_kernel(const ClosedArg
         UVS_WIDE_FENCE();
         double rs[N];
         const bool suspect = chol_factor<N, DH>(G, rs);          // (wide shape: pivot spread only -- no register left for the column-norm watch, see chol_factor; the (8,6) latency kernel has them)
-        flagged |= alive && suspect;                               // ill-conditioned Jacobian: the careful second pass redoes this trial
         chol_solve_inplace<N>(G, rs, b);                           // s0
         if constexpr (SPREAD_STORES) piece(std::integral_constant<int, R + 1>{});
         double c[N];
@@ -477,6 +476,20 @@ __global__ __launch_bounds__(64, 1) void closed_loop_wide_kernel(const ClosedArg
             for (int j = 0; j < N; ++j) c[j] = group_sum<L>(c[j]);
         }
         chol_solve_inplace<N>(G, rs, c);
+        // Refinement watch (round 6; the normal equations' answer to Spread::grows of the QR solvers).  A Kahan-like Jacobian (unit-diagonal
+        // triangle, large off-diagonals: condition 1e19) leaves every Cholesky PIVOT at an ordinary value -- the spread test above sees nothing, and
+        // because squaring J has already destroyed its smallest singular value, the solution does not even grow much.  What gives it away is that
+        // the refinement step does not converge: the correction is cond(J)^2 eps of the solution -- at most 7e-14 on healthy (32,7) closed loops,
+        // at least 2e-3 on every step of Kahan-like ones that does not break the factorisation outright (tests/growth_watch_study.py --wide).
+        // Gate: |correction| >= 2^-20 |s0|, i.e. cond(J) ~ 1e5, a little ahead of the pivot gate (2^20); numpy's pinv (experiment.py:312)
+        // truncates from 1e15, and the careful pass that redoes a marked trial decides that by SVD.
+        {
+            double s_max = 0.0, c_max = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) { s_max = fmax(s_max, fabs(b[j])); c_max = fmax(c_max, fabs(c[j])); }
+            const bool stalls = (unsigned)__double2hiint(c_max) + kRefineGate >= (unsigned)__double2hiint(s_max) && c_max > 0.0;
+            flagged |= alive && (suspect || stalls);               // ill-conditioned Jacobian: the careful second pass redoes this trial
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) dq[j] = -fp.gain * (b[j] + c[j]);
 
