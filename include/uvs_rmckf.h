@@ -169,6 +169,12 @@ int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant 
 /* Lanes per filter the closed-loop call would use for this (fp, plant, T) -- lanes_per_filter, the shape's default, or 4 for a small batch
  * (see UVS_OPT_LATENCY above); 0 when the shape is not instantiated.  Host-side query. */
 int uvs_rmckf_closed_loop_lanes(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
+/* Health of a segmented launch.  A later segment that does not see its predecessor's hand-over within ~65 ms recomputes the trial from step 0
+ * (results stay bit-identical; the path exists so that nothing ever hangs) -- silently, which on a GPU shared between processes or under a
+ * debugger could turn a launch quadratic without anybody noticing.  The launch therefore counts such items: byte offset into the workspace
+ * of an int32 that uvs_rmckf_closed_loop_ws_f64 zeroes and every fallen-back work item increments (0 = this launch is not segmented).  Read it
+ * after the stream has finished; expected 0 (bench.py reports it, the tests assert it). */
+size_t uvs_rmckf_closed_loop_fallback_offset(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T);
 int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T,
                                  uvs_view q_start, uvs_view noise, uvs_view x0,
                                  uvs_view x_out, uvs_view err_out, uvs_view q_out, uvs_view f_out, uvs_view dq_out,
@@ -227,6 +233,13 @@ int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const do
 
 /* noise.py:7-12 (NoiseType) */
 enum { UVS_NOISE_WHITE = 1, UVS_NOISE_GAUSSIAN_MIXTURE = 2, UVS_NOISE_GAUSSIAN_BIMODAL = 3, UVS_NOISE_ALPHA_STABLE = 4, UVS_NOISE_UNIFORM = 5 };
+/* Option bit of uvs_noise_params.type (the low byte is the noise type).  UVS_NOISE_OPT_AS_WRITTEN: evaluate the general Chambers-Mallows-Stuck
+ * branches of ALPHA_STABLE the way noise.py:188-199 writes them -- library sin / cos / log, two library pow(), the reference's order of
+ * operations -- instead of folding the two powers into one exponential.  The default kernels agree with numpy to <= 5e-13 relative (up to a
+ * few dozen ulp in the far tails, where the folded exponent is large); this variant stays within a few ulp everywhere (numpy's own scalar /
+ * SIMD spread is <= 2 ulp), at the generator cost recorded in profiles/r06/noise_as_written.txt.  Other types and the special cases of
+ * ALPHA_STABLE (alpha = 2, Cauchy, Levy, alpha = 1 with skew) already call the library functions and ignore the bit. */
+#define UVS_NOISE_OPT_AS_WRITTEN 0x100
 
 /* Parameters of NoiseProfiler (noise.py:31-79).  The derived fields are filled by the host with the same Python float
  * arithmetic the reference uses, so that no rounding differs: inv_alpha = 1/alpha, expo = (1-alpha)/alpha,
@@ -253,8 +266,8 @@ int uvs_pcg64_seed_u64(int64_t n, const uint64_t *seeds, uint64_t *states, void 
  *          (noise.py:66-70) followed, for the mixtures, by PCG64(2*seed_t + i) for i < m (noise.py:55-59);
  *   zig    768 doubles (device): numpy's ziggurat tables fi[256], wi[256], ki[256] (ki as raw uint64 bits).
  * Uniform, normal and mixture streams reproduce numpy bit for bit (tail samples of the normal to 1-2 ulp); Cauchy and the
- * Chambers-Mallows-Stuck transforms agree to <= 5e-13 relative (device libm vs host libm; the CMS powers are folded into one
- * exponential, which costs up to ~40 ulp in the far tails).
+ * Chambers-Mallows-Stuck transforms agree to <= 5e-13 relative (device libm vs host libm; by default the CMS powers are folded into one
+ * exponential, which costs up to a few dozen ulp in the far tails -- UVS_NOISE_OPT_AS_WRITTEN above evaluates them as the reference writes them).
  */
 int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream);
 
@@ -274,7 +287,8 @@ int uvs_noise_generate_streams_f64(const uvs_noise_params *np, int64_t S, const 
 /*
  * Which instantiation uvs_noise_generate_f64 launches for these parameters (host-side query, no GPU work): 0 = the kernel of np->type,
  * 1 = the alpha-stable kernel specialised for beta = 0 (noise.py:188-191), which evaluates cos((1 - alpha) V) by the addition theorem;
- * it is selected only where that costs < 2e-14 relative (alpha from about 0.1 to 1.999, not 1 or 2).  <0 on bad arguments.
+ * it is selected only where that costs < 2e-14 relative (alpha from about 0.1 to 1.999, not 1 or 2); 2 = the as-written kernel
+ * (UVS_NOISE_OPT_AS_WRITTEN on a general Chambers-Mallows-Stuck parameter set).  <0 on bad arguments.
  */
 int uvs_noise_kernel_variant(const uvs_noise_params *np);
 

@@ -61,7 +61,7 @@ def job_config(name):
 def reduce_csv(path):
     """plot_errorbar.m:20-98 on the reference's results.csv, plus the per-trial rows."""
     import pandas as pd
-    df = pd.read_csv(path)
+    df = pd.read_csv(path, float_precision='round_trip')             # the default parser is fast and up to an ulp off; repr text round-trips exactly
     ids = df['experiment_id'].to_numpy()
     T = int(ids.max()) + 1
     start = np.searchsorted(ids, np.arange(T))                          # rows of a trial are contiguous and in order (main.py:196)

@@ -372,7 +372,12 @@ def test_lost_hand_over_falls_back_to_recomputation(uvs, method, segments):
         outs.append(uvs.engine.closed_loop(fp, plant, _cuda(q0), _cuda(noise.transpose(1, 2, 0)), want=('x', 'err', 'q')))
         torch.cuda.synchronize()
         outs[-1]['wall'] = time.perf_counter() - t0
+        outs[-1]['fallbacks'] = uvs.engine.hand_over_fallbacks(fp, plant, T)
     a, b, c = outs
+    # the launch counts the items that fell back (uvs_rmckf_closed_loop_fallback_offset): none on a healthy launch, every later segment of every
+    # chunk when the first counter is withheld (an item that fell back hands nothing over, so its successors fall back too)
+    chunks = (2 * T + 63) // 64
+    assert a['fallbacks'] is None and b['fallbacks'] == 0 and c['fallbacks'] == chunks * (segments - 1), (a['fallbacks'], b['fallbacks'], c['fallbacks'])
     assert c['wall'] > 0.03, 'the diagnostic bit did not take the fallback (a hand-over that waits out its budget lasts > 30 ms)'
     assert c['wall'] < 2.0, 'fallback after the spin budget must come within a watchdog\'s patience'
     live = torch.arange(K, device='cuda')[:, None, None] < a['k_done'][None, None, :]

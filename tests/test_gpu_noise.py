@@ -38,6 +38,32 @@ def test_device_streams_match_reference(uvs, name, layout):
     assert not np.array_equal(got[0], got[1])
 
 
+@pytest.mark.parametrize('name', [n for n in golden_names('noise_') if 'alpha' in n])
+def test_as_written_variant_matches_reference_within_a_few_ulp(uvs, name):
+    """UVS_NOISE_OPT_AS_WRITTEN (round 6): the Chambers-Mallows-Stuck powers evaluated as noise.py:188-199 writes them -- the reference's alpha-stable
+    fixtures within 6 ulp sample by sample (the folded default: 2e-13 relative, i.e. hundreds of ulp allowed), the shared-stream generator
+    included; special cases (alpha = 2, Cauchy) are untouched by the bit."""
+    g = load_golden(name)
+    meta = g['meta']
+    K = len(g['values'])
+    nt = uvs.NoiseType[meta['noise_type']]
+    out = uvs.noise_device.generate(nt, meta['noise_params'], [meta['seed'], meta['seed'] + 1], meta['m'], K, meta['hold'], meta['hold_cnt'], as_written=True)
+    got = uvs.engine.as_tkc(out).cpu().numpy()[0]
+    ulp = np.abs(np.ascontiguousarray(got).view(np.int64) - np.ascontiguousarray(g['values']).view(np.int64))
+    q = uvs.noise_device.make_noise_params(nt, meta['noise_params'], meta['m'], K, as_written=True)
+    a, b = meta['noise_params'].get('alpha'), meta['noise_params'].get('beta', 0)
+    general = a not in (1, 2) and not (a == 0.5 and abs(b) == 1)
+    if general:
+        print(f'{name}: as-written variant max {int(ulp.max())} ulp, exact {float((ulp == 0).mean()):.3f}')
+        assert ulp.max() <= 6, (name, int(ulp.max()))
+    else:                                                           # the bit changes nothing there: the default kernels' gate
+        assert np.allclose(got, g['values'], rtol=2e-13, atol=0)
+    assert q.type == 4 | 0x100 and uvs.lib().uvs_noise_kernel_variant(q) == (2 if general else 0)
+    if not meta['hold'] and meta['m'] > 2:
+        _, view = uvs.noise_device.generate_shared(nt, meta['noise_params'], meta['seed'], 2, meta['m'], K, as_written=True)
+        assert np.array_equal(view.permute(2, 0, 1).cpu().numpy()[0], got)
+
+
 @pytest.mark.parametrize('kind,params,hold', [
     ('ALPHA_STABLE', dict(alpha=1.5, beta=0, gamma=1, delta=0), False),
     ('ALPHA_STABLE', dict(alpha=1.0, beta=0, gamma=1, delta=0), True),

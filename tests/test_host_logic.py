@@ -61,13 +61,16 @@ def test_workspace_query_is_host_logic(uvs):
     mckf = uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8))
     assert q(mckf, 32768) == 0                                             # one round of wavefronts: nothing to balance
     assert [seg(mckf, T) for T in (32768, 32769, 65536, 98304, 98305, 1048576)] == [1, 8, 8, 8, 4, 4]
-    assert q(mckf, 65536) == 2048 * 4 + 2048 * per_chunk                   # flags + state
-    assert q(mckf, 65537) == (2049 * 4 + 255) // 256 * 256 + 2049 * per_chunk
+    flags = lambda chunks: ((chunks + 1) * 4 + 255) // 256 * 256          # noqa: E731 -- one hand-over counter per chunk + the fallback count (round 6)
+    assert q(mckf, 65536) == flags(2048) + 2048 * per_chunk                # flags + state
+    assert q(mckf, 65537) == flags(2049) + 2049 * per_chunk
+    off = lambda fp, T: int(lib.uvs_rmckf_closed_loop_fallback_offset(ctypes.byref(fp), ctypes.byref(plant), T))   # noqa: E731
+    assert off(mckf, 65536) == 2048 * 4 and off(mckf, 32768) == 0 and off(mckf, 65537) == 2049 * 4               # right behind the chunks' counters; 0 = not segmented
     assert q(uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8)), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 65536) == 0
     # RMCKF: wavefronts of equal length, so only launches that are not a whole number of rounds (1 024 wavefronts of 32 trials) are cut -- in four
     rm = uvs.engine.make_params(8, 6, 'GMCKF', desired=np.zeros(8))
     assert [seg(rm, T) for T in (16384, 32768, 36000, 40000, 49152, 65536, 65536 + 2048, 81920, 98304, 131072 + 16384, 196608 + 16384, 16385)] == [1, 1, 1, 4, 4, 1, 1, 4, 1, 4, 1, 1]
-    assert q(rm, 49152) == 1536 * 4 + 1536 * per_chunk and seg(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 49152) == 1
+    assert q(rm, 49152) == flags(1536) + 1536 * per_chunk and seg(uvs.engine.make_params(8, 6, 'KF', desired=np.zeros(8)), 49152) == 1
     rm.reserved = 1                                                        # strict pinv: everything goes to the careful kernels, nothing to cut
     assert seg(rm, 49152) == 1
     assert q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=4), 65536) == 0 and q(uvs.engine.make_params(8, 6, 'MCKF', desired=np.zeros(8), lanes=-2), 65536) == 0
@@ -393,3 +396,21 @@ def test_sweep_pieces_cover_a_shard_cell_by_cell():
                 if cap is None or cap >= 150:                        # whole cells: one piece per cell the shard touches
                     assert len(pieces) == len(set(plan.cell[lo:hi]))
     assert batch.sweep_pieces(plan, 5, 5) == []
+
+
+def test_counter_figures_belong_to_this_library(uvs):
+    """profiles/traffic_latest.json feeds bench.py's roofline.traffic / roofline.valu with PMC counts of an EARLIER profiling call.  They are valid
+    only for the kernels they were counted on: the file records the fingerprint of the kernel sources it was taken with (csrc/src_hash.py:
+    comments and blank space stripped), the library carries the same fingerprint in uvs_version(), and this test fails when the sources, the
+    built library and the counter file do not all agree -- so the counts cannot outlive a kernel change (VERDICT r5 #6b)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('src_hash', os.path.join(ROOT, 'uncalibrated-visual-servoing_amd', 'csrc', 'src_hash.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    version = uvs.lib().uvs_version().decode()
+    assert version.endswith('src:' + mod.source_hash()), 'libuvs_rmckf.so is older than its sources: rebuild (make -C uncalibrated-visual-servoing_amd/csrc)'
+    tr = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_latest.json')))
+    assert tr.get('library_version') == version, ('profiles/traffic_latest.json was counted on other kernels: re-run tools/profile_round.sh + '
+                                                  'tools/make_traffic_json.py', tr.get('library_version'), version)
+    assert tr['kernel'].startswith('closed_loop_tuned_kernel<8,6,2,GMCKF') and tr['round'] >= 6

@@ -14,7 +14,54 @@ import numpy as np  # noqa: E402
 import uvs_amd as uvs  # noqa: E402
 
 
+def ulp_study(samples=100_000_000):
+    """`python tools/fuzz_noise.py --ulp [samples per alpha]`: ulp distance between the device generator and the host restatement of
+    noise.py (numpy scalar arithmetic, bit-exact against the reference fixtures) over >= 1e8 alpha-stable samples per alpha, for the default
+    kernels (Chambers-Mallows-Stuck powers folded into one exponential) and the as-written variant (UVS_NOISE_OPT_AS_WRITTEN), and what each
+    costs on one sweep cell (65 536 trials: the T + 70 shared streams x 299 steps)."""
+    import torch
+    NT = uvs.NoiseType
+    K, m = 299, 8
+    T = max(64, samples // (K * m))
+    for alpha in (1.0909090909090908, 1.5, 1.9090909090909092):
+        params = dict(alpha=alpha, beta=0.0, gamma=1.0, delta=0.0)
+        worst = {False: [], True: []}
+        done = 0
+        for lo in range(0, T, 4096):                                         # host generation in blocks (noise_batch: ~1.5 M samples/s per core)
+            seeds = 123456 + np.arange(lo, min(T, lo + 4096), dtype=np.int64) * 80      # disjoint generator seeds (seed + 10 i, i < 8)
+            host = uvs.noise_batch(NT.ALPHA_STABLE, params, seeds, m, K)
+            hi = host.view(np.int64)
+            for aw in (False, True):
+                dev = uvs.engine.as_tkc(uvs.noise_device.generate(NT.ALPHA_STABLE, params, seeds, m, K, as_written=aw), 'kct').cpu().numpy()
+                d = np.abs(np.ascontiguousarray(dev).view(np.int64) - hi)        # same sign (checked below): distance in ulp
+                assert np.array_equal(np.sign(dev), np.sign(host))
+                worst[aw].append((int(d.max()), float((d == 0).mean()), float((d <= 1).mean()), float((d <= 2).mean()), float(np.quantile(d, 0.9999)),
+                                  float(np.abs(host.ravel()[np.argmax(d)]))))
+            done += host.size
+        for aw in (False, True):
+            w = np.array(worst[aw])
+            print(f'alpha {alpha:.4f} {"as written" if aw else "folded    "}: {done / 1e6:.0f} M samples, max {int(w[:, 0].max())} ulp (at |x| = {w[np.argmax(w[:, 0]), 5]:.3g}), '
+                  f'99.99 % <= {w[:, 4].max():.0f} ulp, exact {w[:, 1].mean():.4f}, <= 1 ulp {w[:, 2].mean():.4f}, <= 2 ulp {w[:, 3].mean():.4f}', flush=True)
+    # cost of one sweep cell's noise (the shared T + 70 streams) and of the dense per-trial generation
+    params = dict(alpha=1.5, beta=0.0, gamma=1.0, delta=0.0)
+    for label, fn in (('shared streams (65 536 + 70) x 299', lambda aw: uvs.noise_device.generate_shared(NT.ALPHA_STABLE, params, 123456, 65536, m, K, as_written=aw)),
+                      ('dense 65 536 x 8 x 299', lambda aw: uvs.noise_device.generate(NT.ALPHA_STABLE, params, 123456 + np.arange(65536), m, K, as_written=aw))):
+        for aw in (False, True):
+            for _ in range(3):
+                fn(aw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn(aw)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f'{label}, {"as written" if aw else "folded    "}: {e0.elapsed_time(e1) / 10:.3f} ms per call (seeding included)', flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--ulp':
+        return ulp_study(int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     NT = uvs.NoiseType
@@ -43,6 +90,11 @@ def main():
         dev = uvs.engine.as_tkc(uvs.noise_device.generate(kind, params, seeds, m, K, hold, hold_cnt, layout=layout, device='cuda'), layout).cpu().numpy()
         n += host.size
         tag = (case, kind.name, params, m, T, K, hold, hold_cnt, layout)
+        if kind == NT.ALPHA_STABLE:                                  # the as-written variant: the same gate (it is tighter in fact: --ulp measures it)
+            aw = uvs.engine.as_tkc(uvs.noise_device.generate(kind, params, seeds, m, K, hold, hold_cnt, layout=layout, device='cuda', as_written=True), layout).cpu().numpy()
+            fin_aw = np.isfinite(host)
+            if not np.array_equal(np.isfinite(aw), fin_aw) or np.any(np.abs(aw[fin_aw] - host[fin_aw]) > 2e-13 * np.abs(host[fin_aw]) + 1e-12 * (1 + abs(params.get('delta', 0.0)))):
+                bad.append(('as-written variant', tag))
         # round 5: where the trials' streams alias (consecutive seeds, one generator per feature, no hold) the shared-stream generator -- T + 10 (m - 1)
         # streams once, in chunks behind a PCG64 jump -- must return the per-trial generator's bits
         if uvs.noise_device.shares_streams(kind, hold, seeds):

@@ -57,6 +57,8 @@ doc = {'round': rnd, 'workload': 'BASELINE config 2, 65536 trials x 299 updates,
                '(MI355X_MICROARCH.md, HBM section: documented for 16 B/lane reads; these are 8 B/lane and the doubled figure lands on the algorithmic read bytes '
                'within 0.5 %, which supports applying it here); fp64 FLOP = 64 lanes x (2 FMA + MUL + ADD + TRANS) wave-instructions'}
 doc.update(head)
+ver = os.path.join(d, 'library_version.txt')                     # written on the GPU box by tools/profile_round.sh: the library the counters were taken on
+doc['library_version'] = open(ver).read().strip() if os.path.exists(ver) else None
 doc['config3'] = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true', 524288, U3 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
 doc['config5'] = entry('closed_loop_wide_kernel<32, 7, 8, 5, true, true', 524288, U2 * 2360, 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>')
 # (MCKF since round 4: 8 work items per trial chunk, grid 2048 x 8 x 64 -- its hand-over traffic, 141 doubles per lane and segment edge out and back, is part of the counters)

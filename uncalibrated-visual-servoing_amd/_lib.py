@@ -64,6 +64,7 @@ SYMBOLS = {
     'uvs_rmckf_closed_loop_lanes': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_closed_loop_segments': (C.c_int, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_closed_loop_workspace_bytes': (C.c_size_t, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
+    'uvs_rmckf_closed_loop_fallback_offset': (C.c_size_t, [C.POINTER(FilterParams), C.POINTER(Plant), _I64]),
     'uvs_rmckf_replay_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 7 + [_VP] * 2 + [View] * 2 + [_VP]),
     'uvs_rmckf_replay_f32': (C.c_int, [C.POINTER(FilterParams), _I64] + [View] * 5 + [_VP] * 2 + [_VP]),
     'uvs_rmckf_step_f64': (C.c_int, [C.POINTER(FilterParams), _I64] + [_VP] * 5 + [_I32, _I32] + [_VP] * 4 + [_VP]),

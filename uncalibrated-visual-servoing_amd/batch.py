@@ -161,17 +161,18 @@ def run_batch(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=('e
     t_log = engine.loop_clock(ex['dt'], ex['t_max'])
     K, Tl = len(t_log), hi - lo
     dev = torch.device(device)
-    if noise_tensor is None and noise_on_device:
-        noise_tensor = device_noise(cfg, plan, lo, hi, K, dev)
-    if noise_tensor is None:
-        host = np.empty((K, m, Tl))
-        trial_noise(cfg, plan, lo, hi, K, host.transpose(2, 0, 1))  # logical [trial][step][m] view of the trial-fastest buffer
-        noise_tensor = torch.as_tensor(host, device=dev)
-    q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
-    x0 = None
-    if not p['initial_guess']:
-        x0 = torch.as_tensor(np.asarray(p['x0'], float).reshape(1, m * n).repeat(Tl, 0), device=dev)
-    out = engine.closed_loop(fp, plant.to_struct(), q0, noise_tensor, x0, want=want)
+    with torch.cuda.device(dev if dev.index is not None else torch.cuda.current_device()):   # the engine launches on the CURRENT device's current stream
+        if noise_tensor is None and noise_on_device:
+            noise_tensor = device_noise(cfg, plan, lo, hi, K, dev)
+        if noise_tensor is None:
+            host = np.empty((K, m, Tl))
+            trial_noise(cfg, plan, lo, hi, K, host.transpose(2, 0, 1))  # logical [trial][step][m] view of the trial-fastest buffer
+            noise_tensor = torch.as_tensor(host, device=dev)
+        q0 = torch.as_tensor(plan.q_start[lo:hi].copy(), device=dev)
+        x0 = None
+        if not p['initial_guess']:
+            x0 = torch.as_tensor(np.asarray(p['x0'], float).reshape(1, m * n).repeat(Tl, 0), device=dev)
+        out = engine.closed_loop(fp, plant.to_struct(), q0, noise_tensor, x0, want=want)
     start, stop = out['events']                                     # HIP events around the kernel launch (output allocation excluded)
     stop.synchronize()
     return BatchResult(plan, lo, hi, t_log, out['stats'], out['status'], out['k_done'],
@@ -228,6 +229,16 @@ class SweepResult:
 
 def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(), lanes=0, device='cuda', max_trials=None,
               share_noise=True, on_piece=None, strict_pinv=False, latency=False, plan=None):
+    """See _run_sweep.  The engine launches on the CURRENT device's current stream: the sweep runs with ``device`` made current, so that the events
+    that order the row copies against the kernels are recorded on the stream the kernels are launched on."""
+    import torch
+    dev = torch.device(device)
+    with torch.cuda.device(dev if dev.index is not None else torch.cuda.current_device()):
+        return _run_sweep(cfg, plant, cells, epoch, rank, world, want, lanes, torch.device('cuda', torch.cuda.current_device()), max_trials, share_noise,
+                          on_piece, strict_pinv, latency, plan)
+
+
+def _run_sweep(cfg, plant, cells, epoch, rank, world, want, lanes, device, max_trials, share_noise, on_piece, strict_pinv, latency, plan):
     """The whole sweep of main.py:104-148 on this rank's GPU, cell after cell through ONE set of device buffers: for each piece (a cell, or
     ``max_trials`` trials of it) device seeding + noise generation (the T + 70 distinct streams where they alias), the closed-loop launch,
     and the per-trial [ISE, IAE, ITAE], status, k_done copied to pinned host memory on a second stream while the next piece computes.
@@ -245,7 +256,16 @@ def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(),
     if method == Method.ANALYTICAL:
         raise NotImplementedError('ANALYTICAL is not an estimator (and crashes in the reference: R is unbound, experiment.py:121)')
     plant = SyntheticPlant.ur10(ex['desired_f']) if plant is None else plant
-    plan = plan_trials(cfg, cells, epoch) if plan is None else plan
+    if plan is None:
+        plan = plan_trials(cfg, cells, epoch)
+    else:                                                          # a plan made earlier must be THIS sweep's: a stale one would silently run other seeds / cells
+        n_cells = len(sweep_cells(NoiseType[nz['type']])) if cells is None else len(cells)
+        per_cell = int(ex['epoch'] if epoch is None else epoch)
+        first_seed = nz['seed']
+        if len(plan) != n_cells * per_cell or len(plan.cells) != n_cells or (cells is not None and not np.array_equal(plan.cells, np.asarray(cells, float))) or \
+                (first_seed is not None and len(plan) and int(plan.seed[0]) != int(first_seed)) or \
+                (len(plan) and not ex['change_q_start'] and not np.array_equal(plan.q_start[0], np.asarray(ex['q_start'], float))):
+            raise ValueError('run_sweep(plan=...): the plan does not belong to this config / cells / epoch')
     lo, hi = dist.shard_range(len(plan), rank, world)
     p = est['estimator_params']
     m, n = len(ex['desired_f']), plant.n_joints
@@ -274,14 +294,13 @@ def run_sweep(cfg, plant=None, cells=None, epoch=None, rank=0, world=1, want=(),
     # two sets of per-trial outputs (a set is copied out while the next piece writes the other), one set of streams, one noise buffer
     S = Tmax + noise_device.SEED_STEP * (m - 1)
     noise_buf = torch.empty(K * max(S, m * Tmax), dtype=torch.float64, device=dev)
+    streams = {k_: engine.alloc_stream(Tmax, K, c, 'kct', dev) for k_, c in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)) if k_ in want}
     sets = []
-    for _ in range(2):
-        d = {k_: engine.alloc_stream(Tmax, K, c, 'kct', dev) for k_, c in (('x', m * n), ('err', m), ('q', n), ('f', m), ('dq', n)) if k_ in want}
+    for _ in range(2):                                             # the streams are allocated ONCE and shared by both sets (7.5 GB of X per 65 536 trials)
+        d = dict(streams)
         d.update(stats=torch.zeros((Tmax, 3), dtype=torch.float64, device=dev), status=torch.zeros(Tmax, dtype=torch.int32, device=dev),
                  k_done=torch.zeros(Tmax, dtype=torch.int32, device=dev))
         sets.append(d)
-    for k_ in want:                                                # the streams are not double-buffered (7.5 GB of X per 65 536 trials)
-        sets[1][k_] = sets[0][k_]
     main = torch.cuda.current_stream(dev)
     copier = _COPY_STREAMS.get(str(dev))                           # one per device, kept: the first use of a new stream costs ~4 ms on the host
     if copier is None:                                             # (queue creation), during which the GPU runs dry

@@ -156,6 +156,10 @@ UVS_DEV double standard_normal(Pcg64 &g, const double *zig) {
 // (config.json: alpha = linspace(1, 2, 12), beta = 0).  The launcher selects it; the step loop then carries none of the run-time
 // case analysis on (alpha, beta), which costs the general instantiation registers, scalar moves and branches on every sample.
 constexpr int kNoiseStableSymmetric = 6;
+// Kernel-internal noise type: ALPHA_STABLE with the Chambers-Mallows-Stuck transform evaluated AS noise.py:188-199 WRITES IT -- three library
+// sin / cos, two library pow(), library log, the reference's order of operations -- instead of the folded exponential of the default kernels.
+// Selected by UVS_NOISE_OPT_AS_WRITTEN in uvs_noise_params.type: closer to numpy's bits in the far tails (tools/fuzz_noise.py --ulp), slower.
+constexpr int kNoiseStableAsWritten = 7;
 
 // Whether the symmetric instantiation's addition-theorem cosine is accurate enough for these parameters (see draw_stable_symmetric).
 inline bool stable_symmetric_fast(const uvs_noise_params &p) {
@@ -185,6 +189,7 @@ template <int TYPE>
 UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const double *zig) {
     const double HALF_PI = 1.5707963267948966, PI = 3.141592653589793;
     if constexpr (TYPE == kNoiseStableSymmetric) return draw_stable_symmetric(p, gens[0]);
+    constexpr bool AS_WRITTEN = (TYPE == kNoiseStableAsWritten);
     switch (TYPE) {
         case UVS_NOISE_WHITE: return 0.0 + p.std * standard_normal(gens[0], zig);
         case UVS_NOISE_UNIFORM: return gens[0].next_double();                              // uniform(): 0 + 1 * u
@@ -212,8 +217,13 @@ UVS_DEV double draw(const uvs_noise_params &p, Pcg64 *gens, Pcg64 &sel, const do
         x = p.beta / (z * z);
     } else {
         const double V = -HALF_PI + PI * gens[0].next_double();
-        const double W = -log_any(0.0 + 1.0 * gens[0].next_double());     // 1.1e-16 <= W <= 36.8, or +inf for a zero draw (probability 2^-53)
-        if (p.alpha != 1.0) {
+        const double u_w = 0.0 + 1.0 * gens[0].next_double();
+        const double W = AS_WRITTEN ? -log(u_w) : -log_any(u_w);           // 1.1e-16 <= W <= 36.8, or +inf for a zero draw (probability 2^-53)
+        if (AS_WRITTEN && p.alpha != 1.0) {
+            // noise.py:188-199 operation for operation (1 / alpha, (1 - alpha) / alpha, 1 - alpha come from the host's Python floats)
+            if (p.beta == 0.0) x = (sin(p.alpha * V) / pow(cos(V), p.inv_alpha)) * pow(cos(V * p.one_minus_alpha) / W, p.expo);
+            else x = p.cms_S * sin(p.alpha * V + p.cms_B) / pow(cos(V), p.inv_alpha) * pow(cos(p.one_minus_alpha * V - p.cms_B) / W, p.expo);
+        } else if (p.alpha != 1.0) {
             // sin(aV + B) / cos(V)^(1/a) * (cos((1-a)V - B) / W)^((1-a)/a), B = 0 and S = 1 when beta = 0 (noise.py:188-199).  The two powers
             // are folded into one exponential, exp(e log(c2 / W) - log(c1) / a): three bounded-argument sincos (|angle| < 3 pi / 2), two logs
             // and one exp instead of three trigonometric calls and two pow(); differs from the reference's evaluation by
@@ -287,8 +297,8 @@ __global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_kernel(const NoiseArgs
 // section 7; uvs_noise_generate_streams_f64).  Rows are stream-fastest: a wavefront writes 512 contiguous bytes per step.
 template <int TYPE>
 __global__ __launch_bounds__(64) UVS_NOISE_OCC void noise_streams_kernel(const NoiseArgs A) {
-    static_assert(TYPE == UVS_NOISE_WHITE || TYPE == UVS_NOISE_ALPHA_STABLE || TYPE == UVS_NOISE_UNIFORM || TYPE == kNoiseStableSymmetric,
-                  "one generator per feature");
+    static_assert(TYPE == UVS_NOISE_WHITE || TYPE == UVS_NOISE_ALPHA_STABLE || TYPE == UVS_NOISE_UNIFORM || TYPE == kNoiseStableSymmetric ||
+                  TYPE == kNoiseStableAsWritten, "one generator per feature");
     const uvs_noise_params &p = A.np;
     const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
     // A.chunks lanes share a stream (stream fastest: a wavefront still writes 512 contiguous bytes per step), each generating its own range of

@@ -826,7 +826,10 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
                 there = __builtin_amdgcn_readfirstlane((int)there) != 0;          // (every lane ran the loads itself)
                 fresh = !there;
-                if (fresh) k_begin = 0;
+                if (fresh) {                                                      // fallback: recompute from step 0 -- and say so: the word behind the chunks'
+                    k_begin = 0;                                                  // counters counts the items that ran out their budget (0 on a healthy launch)
+                    if (lane == 0) atomicAdd(&A.ws_flags[gridDim.x / (unsigned)A.n_seg], 1);
+                }
             }
         }
     };

@@ -29,7 +29,10 @@ void uvs_launch::debug_math(int which, long long n, const double *x, double *y, 
     hipLaunchKernelGGL(uvs::debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, which, n, x, y);
 }
 
-void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+void uvs_launch::noise(const uvs_noise_params &np_in, long long T, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+    uvs_noise_params np = np_in;
+    const int variant = noise_variant(np_in);
+    np.type &= 0xff;                                               // the kernels see the plain noise type
     uvs::NoiseArgs A{np, T, states, zig, out};
     const long long lanes = T * (np.m / 2);
     const dim3 g((unsigned)((lanes + 63) / 64));
@@ -38,7 +41,9 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
         case UVS_NOISE_GAUSSIAN_MIXTURE: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_MIXTURE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_GAUSSIAN_BIMODAL: hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_GAUSSIAN_BIMODAL>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_ALPHA_STABLE:
-            if (noise_variant(np) == 1)
+            if (variant == 2)
+                hipLaunchKernelGGL(uvs::noise_kernel<uvs::kNoiseStableAsWritten>, g, dim3(64), 0, s, A);
+            else if (variant == 1)
                 hipLaunchKernelGGL(uvs::noise_kernel<uvs::kNoiseStableSymmetric>, g, dim3(64), 0, s, A);
             else
                 hipLaunchKernelGGL(uvs::noise_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A);
@@ -47,7 +52,10 @@ void uvs_launch::noise(const uvs_noise_params &np, long long T, const unsigned l
     }
 }
 
-void uvs_launch::noise_streams(const uvs_noise_params &np, long long S, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+void uvs_launch::noise_streams(const uvs_noise_params &np_in, long long S, const unsigned long long *states, const double *zig, uvs::View out, hipStream_t s) {
+    uvs_noise_params np = np_in;
+    const int variant = noise_variant(np_in);
+    np.type &= 0xff;
     uvs::NoiseArgs A{np, S, states, zig, out};
     // draws per sample of the type's generator (noise.py:179-205): uniform and Cauchy 1, the Chambers-Mallows-Stuck transform 2 (V, W); the ziggurat
     // normal (white noise, alpha = 2, the Levy case) consumes a data-dependent number and keeps one lane per stream
@@ -69,7 +77,9 @@ void uvs_launch::noise_streams(const uvs_noise_params &np, long long S, const un
     switch (np.type) {
         case UVS_NOISE_WHITE: hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_WHITE>, g, dim3(64), 0, s, A); break;
         case UVS_NOISE_ALPHA_STABLE:
-            if (noise_variant(np) == 1)
+            if (variant == 2)
+                hipLaunchKernelGGL(uvs::noise_streams_kernel<uvs::kNoiseStableAsWritten>, g, dim3(64), 0, s, A);
+            else if (variant == 1)
                 hipLaunchKernelGGL(uvs::noise_streams_kernel<uvs::kNoiseStableSymmetric>, g, dim3(64), 0, s, A);
             else
                 hipLaunchKernelGGL(uvs::noise_streams_kernel<UVS_NOISE_ALPHA_STABLE>, g, dim3(64), 0, s, A);
@@ -79,7 +89,11 @@ void uvs_launch::noise_streams(const uvs_noise_params &np, long long S, const un
 }
 
 int uvs_launch::noise_variant(const uvs_noise_params &np) {
-    return (np.type == UVS_NOISE_ALPHA_STABLE && uvs::stable_symmetric_fast(np)) ? 1 : 0;
+    if ((np.type & 0xff) != UVS_NOISE_ALPHA_STABLE) return 0;
+    // as written: only the general Chambers-Mallows-Stuck branches differ (alpha = 2, Cauchy, Levy and alpha = 1 with skew already call the library)
+    const bool general = np.alpha != 2.0 && np.alpha != 1.0 && !(np.alpha == 0.5 && (np.beta == 1.0 || np.beta == -1.0));
+    if ((np.type & UVS_NOISE_OPT_AS_WRITTEN) && general) return 2;
+    return uvs::stable_symmetric_fast(np) ? 1 : 0;
 }
 
 void uvs_launch::pcg64_seed(long long n, const unsigned long long *seeds, unsigned long long *states, hipStream_t s) {

@@ -136,7 +136,7 @@ int segments_for(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T)
     if (n > 1 && fp->steps < 8 * n) n = 1;                        // nothing to cut in a short trial
     return n < 1 ? 1 : n;
 }
-size_t seg_flag_bytes(int64_t chunks) { return (size_t)((chunks * sizeof(int) + 255) / 256) * 256; }
+size_t seg_flag_bytes(int64_t chunks) { return (size_t)(((chunks + 1) * sizeof(int) + 255) / 256) * 256; }   // one counter per chunk + the fallback count
 }  // namespace
 
 int uvs_rmckf_closed_loop_segments(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) { return segments_for(fp, plant, T); }
@@ -153,6 +153,11 @@ size_t uvs_rmckf_closed_loop_workspace_bytes(const uvs_filter_params *fp, const 
     if (n <= 1) return 0;
     const int64_t chunks = (T * 2 + 63) / 64;
     return seg_flag_bytes(chunks) + (size_t)chunks * uvs::seg_state_doubles(fp->m, fp->n, 2) * 64 * sizeof(double);
+}
+
+size_t uvs_rmckf_closed_loop_fallback_offset(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T) {
+    if (segments_for(fp, plant, T) <= 1) return 0;
+    return (size_t)((T * 2 + 63) / 64) * sizeof(int);
 }
 
 int uvs_rmckf_closed_loop_f64(const uvs_filter_params *fp, const uvs_plant *plant, int64_t T, uvs_view q_start, uvs_view noise,
@@ -327,7 +332,8 @@ int uvs_stats_reduce_f64(int64_t T, int32_t K, int32_t m, uvs_view err, const do
 int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t *states, const double *zig, uvs_view out, void *stream) {
     if (!np || T <= 0 || !states || !zig || !out.base) return fail(UVS_ERR_ARG, "%s", "bad noise_generate arguments");
     if (np->m <= 0 || np->m % 2 || np->m > UVS_MAX_M || np->steps < 0) return fail(UVS_ERR_ARG, "%s", "noise: m must be even and <= UVS_MAX_M");
-    if (np->type < UVS_NOISE_WHITE || np->type > UVS_NOISE_UNIFORM) return fail(UVS_ERR_ARG, "%s", "unknown noise type");
+    if ((np->type & 0xff) < UVS_NOISE_WHITE || (np->type & 0xff) > UVS_NOISE_UNIFORM || (np->type & ~(0xff | UVS_NOISE_OPT_AS_WRITTEN)))
+        return fail(UVS_ERR_ARG, "%s", "unknown noise type");
     noise(*np, (long long)T, (const unsigned long long *)states, zig, uvs::to_view(out), (hipStream_t)stream);
     return check_launch("noise_kernel");
 }
@@ -335,7 +341,8 @@ int uvs_noise_generate_f64(const uvs_noise_params *np, int64_t T, const uint64_t
 int uvs_noise_generate_streams_f64(const uvs_noise_params *np, int64_t S, const uint64_t *states, const double *zig, double *out, int64_t stream_stride,
                                    int64_t step_stride, void *stream) {
     if (!np || S <= 0 || !states || !zig || !out || np->steps < 0) return fail(UVS_ERR_ARG, "%s", "bad noise_generate_streams arguments");
-    if (np->type != UVS_NOISE_WHITE && np->type != UVS_NOISE_ALPHA_STABLE && np->type != UVS_NOISE_UNIFORM)
+    const int base_type = np->type & 0xff;
+    if ((base_type != UVS_NOISE_WHITE && base_type != UVS_NOISE_ALPHA_STABLE && base_type != UVS_NOISE_UNIFORM) || (np->type & ~(0xff | UVS_NOISE_OPT_AS_WRITTEN)))
         return fail(UVS_ERR_ARG, "%s", "noise streams: only the types with one generator per feature (WHITE_NOISE, ALPHA_STABLE, UNIFORM)");
     if (np->hold_cnt != 0) return fail(UVS_ERR_ARG, "%s", "noise streams: the outlier hold couples the two features of a pair; use uvs_noise_generate_f64");
     noise_streams(*np, (long long)S, (const unsigned long long *)states, zig, uvs::View{out, stream_stride, step_stride, 0}, (hipStream_t)stream);
@@ -343,7 +350,8 @@ int uvs_noise_generate_streams_f64(const uvs_noise_params *np, int64_t S, const 
 }
 
 int uvs_noise_kernel_variant(const uvs_noise_params *np) {
-    if (!np || np->type < UVS_NOISE_WHITE || np->type > UVS_NOISE_UNIFORM) return fail(UVS_ERR_ARG, "%s", "bad noise parameters");
+    if (!np || (np->type & 0xff) < UVS_NOISE_WHITE || (np->type & 0xff) > UVS_NOISE_UNIFORM || (np->type & ~(0xff | UVS_NOISE_OPT_AS_WRITTEN)))
+        return fail(UVS_ERR_ARG, "%s", "bad noise parameters");
     return noise_variant(*np);
 }
 

@@ -110,6 +110,20 @@ def workspace(fp, plant_struct, T, device):
     return buf.data_ptr(), need
 
 
+def hand_over_fallbacks(fp, plant_struct, T, device=None):
+    """Work items of the LAST segmented launch of this (fp, plant, T) on this stream that ran out their spin budget and recomputed their trial
+    from step 0 (uvs_rmckf_closed_loop_fallback_offset): 0 on a healthy launch, None when the launch is not segmented.  Synchronises."""
+    torch = _torch()
+    off = int(_lib.lib().uvs_rmckf_closed_loop_fallback_offset(C.byref(fp), C.byref(plant_struct), T))
+    if off == 0:
+        return None
+    device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    buf = _WORKSPACES.get((str(device), torch.cuda.current_stream().cuda_stream))
+    if buf is None:
+        return None
+    return int(buf[off:off + 4].view(torch.int32).item())
+
+
 def launch_closed_loop(fp, plant_struct, T, *args, device=None):
     """uvs_rmckf_closed_loop_ws_f64 on torch's current stream with this process's cached workspace: ``args`` are the views / pointers of
     uvs_rmckf_closed_loop_f64 between ``T`` and ``stream``, in the header's order.  Returns the library's return code."""
@@ -121,8 +135,9 @@ def launch_closed_loop(fp, plant_struct, T, *args, device=None):
 def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False, x_layout=None, reuse=None):
     """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
     ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``).
-    ``x_layout``: another layout for the X stream alone -- 'ktc' (per-trial records) is the fast store path of the (8,6) KF / IMCC-KF / RMCKF
-    kernels, whatever the layout of the narrow streams (which are coalesced as trial-fastest rows).
+    ``x_layout``: another layout for the X stream alone.  'ktc' (per-trial records) is the faster store path of the (8,6) KF and IMCC-KF kernels
+    on batches above 16 384 trials (two lanes per filter; -2.3 % / -0.7 %, profiles/r05/record_layout.txt) -- and only there: RMCKF and MCKF keep
+    their strided stores whatever the view, and smaller batches run on the four-lane kernels, for which 'ktc' is an uncoalesced, slower path.
     ``reuse``: the dict an earlier call with at least as many trials returned -- its tensors are written again ([..., :T] of the streams,
     [:T] of the per-trial arrays) instead of allocating new ones (batch.run_sweep: cell after cell through one set of buffers)."""
     x_layout = x_layout or layout
