@@ -938,6 +938,21 @@ def main():
                     others[key]['x_records'] = {'avg_kernel_ms': rec_ms, 'frac': upd * b_alg / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'x_layout': 'ktc'}
                 noise = noise_head
             fp = fp_head
+            # UVS_OPT_STRICT_PINV on the headline workload: every control-law solve certified in-kernel (round 6) against the default mode's watches
+            fp_strict = type(fp).from_buffer_copy(fp)
+            fp_strict.reserved |= 1
+            fp = fp_strict
+            ms = []
+            for i in range(2 + 5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch()
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 2:
+                    ms.append(e0.elapsed_time(e1))
+            fp = fp_head
+            others['strict_pinv'] = {'avg_kernel_ms': float(np.mean(ms)), 'x_default': float(np.mean(ms)) / avg_ms, 'failed_trials': int((status != 0).sum().item())}
         shard_model = None
         if side_ok and not args.e2e:
             # What ONE GPU does with the shard a rank of north_star's strong series would own (65 536 / N trials): kernel time per launch on the

@@ -49,12 +49,18 @@ enum { UVS_METHOD_ANALYTICAL = 1, UVS_METHOD_KF = 2, UVS_METHOD_MCKF = 3, UVS_ME
 enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
 
 /* Option bits of uvs_filter_params.reserved.
- * UVS_OPT_STRICT_PINV: every control-law solve of the closed loop / of a replay that asks for the commanded dq goes through the careful
- *   kernels (Householder QR finished by an SVD of the triangular factor with numpy's 1e-15 cutoff, experiment.py:312) instead of only
- *   the trials the fast kernels' watches mark.  The watches see a vanishing pivot, bad column scaling and -- since round 5 -- a solution
- *   that grows by 2^34 against its right-hand side, which also catches the Kahan-like Jacobian (tests/golden/rankdef_gmckf_kahan_c1000) whose
- *   entries give nothing away; strict mode remains as a cross-check.  It re-runs whole trials through the generic kernel and is an order of
- *   magnitude slower; default off. */
+ * UVS_OPT_STRICT_PINV: numpy's pinv semantics (experiment.py:312: SVD, singular values <= 1e-15 sigma_max dropped) PROVEN on every control-law
+ *   solve instead of watched for.  In the tuned QR kernels (lanes_per_filter 1 / 2 / 4 at (8,6) and (6,6); MCKF at (8,6) on the DH plant) every
+ *   solve carries a certificate: cond_2(R) <= |R|_F |R^-1|_F, evaluated from the inverse of the triangular factor; below 2^42 nothing can be
+ *   truncated, so the least-squares command IS pinv's; anything else marks the trial for the careful pass, which decides by a Jacobi SVD of the
+ *   factor.  Costs 3-13 % of a launch (profiles/r06/strict_certificate_ab.txt; round 5: 16 x) -- cheap enough to audit the default mode's watches
+ *   at full size (tests/test_gpu_rankdef.py::test_strict_pinv_audit_at_full_size: 65 536 trials, bit-identical).  Kernels without the certificate
+ *   (the wide shape's normal equations, the generic templates, the replay) send every trial through the careful kernels instead, an order of
+ *   magnitude slower.  Default off: the default mode WATCHES every solve -- QR kernels: a vanishing pivot, bad column scaling, a solution that
+ *   grows by 2^34 against its right-hand side (catches the Kahan-like Jacobian of tests/golden/rankdef_gmckf_kahan_c1000, whose entries give
+ *   nothing away); normal-equation kernels (the (32,7) closed loop, the replay's control wavefronts): the spread of the Cholesky pivots, a
+ *   factorisation that breaks down, and (round 6) a refinement step that does not converge (correction >= 2^-20 of the solution), which is how a
+ *   Kahan-like Jacobian shows there -- and re-runs only the trials it marks. */
 #define UVS_OPT_STRICT_PINV 1
 /* Small batches.  A closed-loop batch of the (8,6) shape that does not fill the chip (at most 16 384 trials; every estimator on the DH
  *   plant, lanes_per_filter == 0; MCKF too since round 5) runs with four lanes per filter instead of two -- half the trials per wavefront, twice the
@@ -141,8 +147,8 @@ int uvs_supported_lanes(int32_t m, int32_t n, int32_t *lanes, int32_t cap);
  *   x_final  [T][1][m*n], p_final [T][1][m*n*n] out  state after the last step (NULL to skip)
  *
  * numpy.linalg.pinv semantics (experiment.py:312: SVD, singular values <= 1e-15 * sigma_max dropped).  The kernels solve the control law
- * by Householder least squares, which equals pinv(J) y for full column rank.  Every solve watches the spread of the factor's entries and the
- * growth of its solution against its right-hand side; a trial in which either reaches 2^34 (or a column vanishes) is marked and re-run from its first step by a second, careful kernel that the call enqueues
+ * by Householder least squares (the (32,7) shape: normal equations with one refinement step), which equals pinv(J) y for full column rank.
+ * Every solve is watched (see UVS_OPT_STRICT_PINV above for what each kind of kernel watches); a trial that trips a watch is marked and re-run from its first step by a second, careful kernel that the call enqueues
  * right behind the first: its control law finishes the QR with a Jacobi SVD of the n x n factor and applies numpy's cutoff, i.e. it
  * returns the truncated minimum-norm command the reference computes for a (numerically) rank-deficient Jacobian.  Healthy trials are not
  * touched by the second pass; the marks never leave the library.

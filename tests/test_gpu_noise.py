@@ -54,8 +54,11 @@ def test_as_written_variant_matches_reference_within_a_few_ulp(uvs, name):
     a, b = meta['noise_params'].get('alpha'), meta['noise_params'].get('beta', 0)
     general = a not in (1, 2) and not (a == 0.5 and abs(b) == 1)
     if general:
-        print(f'{name}: as-written variant max {int(ulp.max())} ulp, exact {float((ulp == 0).mean()):.3f}')
-        assert ulp.max() <= 6, (name, int(ulp.max()))
+        # (gamma x + delta cancels near zero when delta != 0, noise.py:205: the 6 ulp are those of |value| + |delta|)
+        room = np.spacing(np.abs(g['values']) + abs(meta['noise_params'].get('delta', 0.0)))
+        worst = float((np.abs(got - g['values']) / room).max())
+        print(f'{name}: as-written variant max {worst:.1f} ulp, exact {float((ulp == 0).mean()):.3f}')
+        assert worst <= 6, (name, worst)
     else:                                                           # the bit changes nothing there: the default kernels' gate
         assert np.allclose(got, g['values'], rtol=2e-13, atol=0)
     assert q.type == 4 | 0x100 and uvs.lib().uvs_noise_kernel_variant(q) == (2 if general else 0)

@@ -607,7 +607,7 @@ def test_full_size_batch_properties(uvs):
     assert int((full['status'] != 0).sum()) < T // 100
 
 
-@pytest.mark.parametrize('method,max_failed,min_calm', [('GMCKF', 65, 0.95), ('MCKF', 1000, 0.95), ('KF', 65, 0.95), ('IMCCKF', 65, 0.95)])
+@pytest.mark.parametrize('method,max_failed,min_calm', [('GMCKF', 65, 0.975), ('MCKF', 1000, 0.98), ('KF', 65, 0.975), ('IMCCKF', 65, 0.985)])
 def test_full_size_config2_product_noise_all_299_steps(uvs, method, max_failed, min_calm):
     """BASELINE config 2 exactly as bench.py runs it (VERDICT r3 #7a), and (round 5) the same launch for the other three estimators -- MCKF
     as the library's 8 tapered work items per trial at full size: 65 536 trials on the PRODUCT's alpha = 1.5 generator, global seeds

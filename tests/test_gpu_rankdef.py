@@ -202,3 +202,40 @@ def test_wide_shape_closed_loop_on_a_kahan_like_jacobian(uvs, lanes):
         assert rel_err(out['x'].cpu().numpy()[:, :, t], ref['X']) <= tol, t
     dq0 = out['dq'].cpu().numpy()[0, :, sick]
     assert np.abs(dq0).max() < 1e-3                                        # numpy's truncated command, not the plain one (0.05)
+
+
+@pytest.mark.parametrize('method,alpha', [('GMCKF', 1.5), ('GMCKF', 1.0), ('MCKF', 1.0), ('KF', 1.0)])
+def test_strict_pinv_audit_at_full_size(uvs, method, alpha):
+    """The audit UVS_OPT_STRICT_PINV exists for, at BASELINE config 2's size.  Since round 6 strict mode CERTIFIES every
+    control-law solve in the tuned kernels -- |R|_F |R^-1|_F < 2^42 proves that numpy's pinv (experiment.py:312) truncates nothing, so the
+    least-squares command is pinv's -- and sends only what it cannot certify to the SVD pass.  65 536 trials x 299 solves: the strict launch
+    returns the default launch's streams, statistics, status and k_done BIT FOR BIT (a trial the certificate marked would come back from the
+    careful kernel with other last bits), i.e. the default mode's watches missed nothing the certificate sees; and it costs at most 2 x."""
+    import torch
+    import bench
+    cfg = bench.config2()
+    cfg['estimator']['method'] = method
+    cfg['noise']['noise_params']['alpha'] = alpha
+    plan = uvs.batch.plan_trials(cfg, cells=[alpha])
+    T, K = len(plan), 299
+    noise = uvs.batch.device_noise(cfg, plan, 0, T, K, 'cuda')
+    q0 = _cuda(plan.q_start)
+    plant = uvs.SyntheticPlant.ur10(cfg['experiments']['desired_f']).to_struct()
+    outs, ms = [], []
+    for strict in (False, True):
+        fp = uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, 0)
+        fp.reserved = (1 if strict else 0) | (1 << 8)                # whole trials in both (strict mode never cuts MCKF trials into work items)
+        uvs.engine.closed_loop(fp, plant, q0, noise, want=('err',))
+        out = uvs.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))
+        torch.cuda.synchronize()
+        ms.append(out['events'][0].elapsed_time(out['events'][1]))
+        outs.append(out)
+    a, b = outs
+    assert torch.equal(a['status'], b['status']) and torch.equal(a['k_done'], b['k_done'])
+    live = torch.arange(K, device='cuda')[:, None, None] < a['k_done'][None, None, :]
+    for key in ('x', 'err', 'q'):
+        assert torch.equal(torch.where(live, a[key], 0.0).view(torch.int64), torch.where(live, b[key], 0.0).view(torch.int64)), key
+    ok = a['status'] == 0
+    assert torch.equal(a['stats'][ok].view(torch.int64), b['stats'][ok].view(torch.int64))
+    print(f'strict-pinv audit, {method} alpha {alpha}: {T} trials bit-identical to the default mode; {ms[1]:.2f} ms against {ms[0]:.2f} ms ({ms[1] / ms[0]:.2f} x)')
+    assert ms[1] <= 2.0 * ms[0]

@@ -495,7 +495,7 @@ UVS_DEV void rmckf_row(double (&x)[N], double (&pb)[Sym<N>::NP], const double (&
 // of an earlier column at the latest, every remaining row of column j, so the squared column norm n2 that column j's own step forms is
 // non-finite: the exponent watch sees it for free, and the closed-loop kernel needs no separate finiteness probe of X (24 instructions per step).
 template <int M, int N, int L>
-UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N], bool &nonfinite) {
+UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[N], bool &nonfinite, bool certify = false) {
     constexpr int R = M / L;
     double rdiag[N];
     double rmax = 0.0;
@@ -566,7 +566,39 @@ UVS_DEV bool lstsq_tall_tuned(double (&a)[M / L][N + 1], int sub, double (&sol)[
     // entry) instead of FAILed here.  An infinite entry in any but the last column turns a later column's norm into NaN (0 * inf in the
     // reflector); in the last column it goes the careful way too and FAILs there, at the same step.
     nonfinite = spread.hi > 0x7ff00000u && spread.lo != 0u;
-    return spread.suspect() || spread.hi == 0x7ff00000u || grows;
+    bool uncertified = false;
+#ifdef UVS_NO_CERTIFICATE               // diagnostic build: A/B of what the cold strict-mode branch costs the plain step (register allocation)
+    certify = false;
+#endif
+    if (__builtin_expect(certify, 0)) {
+        // UVS_OPT_STRICT_PINV (round 6): a CERTIFICATE instead of a heuristic.  numpy's pinv (experiment.py:312) drops singular values below
+        // 1e-15 sigma_max; when none is that small, pinv(J) y IS the least-squares solution just computed.  cond_2(R) <= |R|_F |R^-1|_F, so the
+        // inverse of the triangle, column by column over the rows where they live (the back substitution above, six times, unit right-hand sides),
+        // bounds the condition number from ABOVE: below ~2^42 the solve is certified -- a margin of 2^7 to numpy's cutoff for what rounding does to
+        // the computed inverse at that conditioning -- and anything else marks the trial for the SVD pass, which then decides by the singular
+        // values themselves.  |R|_F^2 <= 21 max^2 comes from the spread's running maximum.  ~170 instructions per step, in strict mode only.
+        double inv2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double z[N];
+            z[k] = rdiag[k];
+            inv2 = fma(z[k], z[k], inv2);
+#pragma unroll
+            for (int c = k - 1; c >= 0; --c) {
+                const int m = c / L, owner = c % L;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = c + 1; j <= k; ++j) acc = fma(a[m][j], z[j], acc);
+                z[c] = -pair_from_dyn<L>(acc, owner) * rdiag[c];
+                inv2 = fma(z[c], z[c], inv2);
+            }
+        }
+        // high dwords add like exponents: certified when max^2 |R^-1|_F^2 < 2^78 up to the fields' slack (a factor 4), i.e. -- with 21 entries in
+        // |R|_F^2 -- when cond^2 < 21 * 2^80 < 2^85
+        const unsigned long long lhs = (unsigned long long)(unsigned)__double2hiint(inv2) + spread.hi;
+        uncertified = !(lhs < 2ull * 0x3ff00000u + (78ull << 20));          // (NaN / inf in either factor compare as "not below")
+    }
+    return spread.suspect() || spread.hi == 0x7ff00000u || grows || uncertified;
 }
 
 template <int M, int N, int L>
@@ -730,7 +762,11 @@ constexpr int kSharedOcc = 2;           // wavefronts per SIMD of the two-lane K
 // rows of a step: 12 stores of 16 bytes per lane, each covering eight whole 128-byte lines, instead of 24 stores of 8 bytes per lane scattered
 // over 48 rows of the trial-fastest layout.  KF / IMCC-KF are bound by the CU's store path; the launcher picks this
 // instantiation when the caller's x_out view has that shape.
-template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false>
+// CERT (round 6): UVS_OPT_STRICT_PINV's certificate (lstsq_tall_tuned) is a uniform run-time branch everywhere except in the MCKF kernel, where
+// even the untaken branch cost the plain step 21 instructions of register shuffling (+ 0.8 %, profiles/r06/strict_certificate_ab.txt): MCKF takes
+// it as a compile-time switch, and the launcher picks the CERT instantiation in strict mode.
+template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false,
+          bool CERT = false>
 __global__ __launch_bounds__(64, (L >= 4 ? kL4Occ : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? kSharedOcc : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
@@ -1647,7 +1683,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             // the per-entry probe `chk` that the rows accumulate is dead code in this kernel.
             bool nonfinite, suspect;
             if constexpr (EMU2) suspect = lstsq_tall_emu2<M, N>(panel, sub, sol, nonfinite);
-            else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite);
+            else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite, METHOD == UVS_METHOD_MCKF ? CERT : (A.fp.reserved & UVS_OPT_STRICT_PINV) != 0);
             if constexpr (METHOD == UVS_METHOD_MCKF) nonfinite |= fpi.poison && !fpi.skip;      // the reference's NaN state after a subnormal weight
             if (alive && nonfinite) {
                 alive = false;

@@ -227,8 +227,17 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
                            (fp->method == UVS_METHOD_MCKF && L == 2)) && fp->lanes_per_filter >= 0;
     const bool linear = plant->kind == UVS_PLANT_LINEAR, xo = x_out.base != nullptr;
     if (fp->lanes_per_filter == 0 && fp->m == 32 && fp->n == 7 && tuned_ok && linear && !fp->initial_guess) L = 8;   // wide-shape tuned kernel
-    if (fp->reserved & UVS_OPT_STRICT_PINV) {                      // numpy's pinv on every solve: mark every trial, the careful pass below is the only pass
-        uvs_launch::fill_i32(status, uvs::UVS_STATUS_SUSPECT, (long long)T, s);
+    if (fp->reserved & UVS_OPT_STRICT_PINV) {
+        // numpy's pinv on every solve.  The tuned QR kernels (lanes 1 / 2 / 4 per filter; not the wide shape's normal equations) CERTIFY every
+        // solve themselves in this mode -- a rigorous upper bound of the condition number from the inverse of the triangular factor, rmckf_tuned.hpp
+        // lstsq_tall_tuned -- and mark what they cannot certify: one fast pass plus the careful pass for the marked trials (round 6; ~1.1 x the
+        // default mode).  Everything else: mark every trial, the careful pass below is the only pass (an order of magnitude slower).
+        const bool wide_takes = (fp->m == 8 && fp->n == 6 && L == 8 && !linear) || (fp->m == 32 && fp->n == 7 && (L == 8 || L == 16) && linear);
+        const bool mckf_has_cert = fp->method != UVS_METHOD_MCKF || (fp->m == 8 && fp->n == 6 && L == 2 && !linear);   // (tu_closed_tuned.inc: the CERT instantiation)
+        bool certified_pass = false;
+        if (tuned_ok && !wide_takes && mckf_has_cert)
+            certified_pass = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
+        if (!certified_pass) uvs_launch::fill_i32(status, uvs::UVS_STATUS_SUSPECT, (long long)T, s);
         launched = true;
     }
 #ifdef UVS_HAVE_EMU2
