@@ -50,7 +50,7 @@ enum { UVS_STATUS_SUCCESS = 0, UVS_STATUS_FAIL = 1 };
 
 /* Option bits of uvs_filter_params.reserved.
  * UVS_OPT_STRICT_PINV: numpy's pinv semantics (experiment.py:312: SVD, singular values <= 1e-15 sigma_max dropped) PROVEN on every control-law
- *   solve instead of watched for.  In the tuned QR kernels (lanes_per_filter 1 / 2 / 4 at (8,6) and (6,6); MCKF at (8,6) on the DH plant) every
+ *   solve instead of watched for.  In the tuned QR kernels (RMCKF: lanes_per_filter 1 / 2 / 4 at (8,6) and (6,6); KF, IMCC-KF, MCKF: the default two lanes at (8,6) on the DH plant) every
  *   solve carries a certificate: cond_2(R) <= |R|_F |R^-1|_F, evaluated from the inverse of the triangular factor; below 2^42 nothing can be
  *   truncated, so the least-squares command IS pinv's; anything else marks the trial for the careful pass, which decides by a Jacobi SVD of the
  *   factor.  Costs 3-13 % of a launch (profiles/r06/strict_certificate_ab.txt; round 5: 16 x) -- cheap enough to audit the default mode's watches

@@ -762,9 +762,10 @@ constexpr int kSharedOcc = 2;           // wavefronts per SIMD of the two-lane K
 // rows of a step: 12 stores of 16 bytes per lane, each covering eight whole 128-byte lines, instead of 24 stores of 8 bytes per lane scattered
 // over 48 rows of the trial-fastest layout.  KF / IMCC-KF are bound by the CU's store path; the launcher picks this
 // instantiation when the caller's x_out view has that shape.
-// CERT (round 6): UVS_OPT_STRICT_PINV's certificate (lstsq_tall_tuned) is a uniform run-time branch everywhere except in the MCKF kernel, where
-// even the untaken branch cost the plain step 21 instructions of register shuffling (+ 0.8 %, profiles/r06/strict_certificate_ab.txt): MCKF takes
-// it as a compile-time switch, and the launcher picks the CERT instantiation in strict mode.
+// CERT (round 6): UVS_OPT_STRICT_PINV's certificate (lstsq_tall_tuned) is a uniform run-time branch in the RMCKF kernels, which it costs nothing
+// (same registers, same main path).  In the MCKF kernel even the untaken branch cost the plain step 21 instructions of register shuffling (+ 0.8 %,
+// profiles/r06/strict_certificate_ab.txt), and the KF / IMCC-KF kernels, held to 256 registers for two wavefronts per SIMD, spilled 12 bytes over
+// it: those three take it as a compile-time switch, and the launcher picks their CERT instantiations in strict mode.
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false,
           bool CERT = false>
 __global__ __launch_bounds__(64, (L >= 4 ? kL4Occ : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? kSharedOcc : 1))
@@ -1683,7 +1684,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             // the per-entry probe `chk` that the rows accumulate is dead code in this kernel.
             bool nonfinite, suspect;
             if constexpr (EMU2) suspect = lstsq_tall_emu2<M, N>(panel, sub, sol, nonfinite);
-            else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite, METHOD == UVS_METHOD_MCKF ? CERT : (A.fp.reserved & UVS_OPT_STRICT_PINV) != 0);
+            else suspect = lstsq_tall_tuned<M, N, L>(panel, sub, sol, nonfinite, METHOD == UVS_METHOD_GMCKF ? (A.fp.reserved & UVS_OPT_STRICT_PINV) != 0 : CERT);
             if constexpr (METHOD == UVS_METHOD_MCKF) nonfinite |= fpi.poison && !fpi.skip;      // the reference's NaN state after a subnormal weight
             if (alive && nonfinite) {
                 alive = false;

@@ -233,9 +233,9 @@ int uvs_rmckf_closed_loop_ws_f64(const uvs_filter_params *fp, const uvs_plant *p
         // lstsq_tall_tuned -- and mark what they cannot certify: one fast pass plus the careful pass for the marked trials (round 6; ~1.1 x the
         // default mode).  Everything else: mark every trial, the careful pass below is the only pass (an order of magnitude slower).
         const bool wide_takes = (fp->m == 8 && fp->n == 6 && L == 8 && !linear) || (fp->m == 32 && fp->n == 7 && (L == 8 || L == 16) && linear);
-        const bool mckf_has_cert = fp->method != UVS_METHOD_MCKF || (fp->m == 8 && fp->n == 6 && L == 2 && !linear);   // (tu_closed_tuned.inc: the CERT instantiation)
+        const bool has_cert = fp->method == UVS_METHOD_GMCKF || (fp->m == 8 && fp->n == 6 && L == 2 && !linear);   // (tu_closed_tuned.inc: the CERT instantiations)
         bool certified_pass = false;
-        if (tuned_ok && !wide_takes && mckf_has_cert)
+        if (tuned_ok && !wide_takes && has_cert)
             certified_pass = closed_tuned_a(fp->m, fp->n, L, fp->method, linear, xo, T, s, A) || closed_tuned_b(fp->m, fp->n, L, fp->method, linear, xo, T, s, A);
         if (!certified_pass) uvs_launch::fill_i32(status, uvs::UVS_STATUS_SUSPECT, (long long)T, s);
         launched = true;
