@@ -883,29 +883,6 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     const bool on_noise = A.noise.p != nullptr, on_err = A.err_out.p != nullptr, on_f = A.f_out.p != nullptr,
                on_q = A.q_out.p != nullptr, on_dq = A.dq_out.p != nullptr;
 
-    double nz_early[R];                                            // the first noise rows of the segment as planned (a fallback reloads those of step 0)
-    const int k_planned = k_begin;
-#pragma unroll
-    for (int r = 0; r < R; ++r) nz_early[r] = 0.0;
-    if (on_noise && k_planned < K) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) nz_early[r] = (pn + (long long)k_planned * A.noise.sk)[r * RS * A.noise.sc];
-    }
-    if constexpr (DH) {
-        if (lane < N) {
-            lds_c[PC::kJoint + 5 * lane + 0] = A.plant.theta_offset[lane];
-            lds_c[PC::kJoint + 5 * lane + 1] = A.plant.d[lane];
-            lds_c[PC::kJoint + 5 * lane + 2] = A.plant.a[lane];
-            lds_c[PC::kJoint + 5 * lane + 3] = A.plant.cos_alpha[lane];
-            lds_c[PC::kJoint + 5 * lane + 4] = A.plant.sin_alpha[lane];
-        }
-        if (lane < M / 2) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) lds_c[PC::kPoint + 3 * lane + c] = A.plant.points[lane][c];
-        }
-        if (lane == 0) { lds_c[PC::kCam] = A.plant.focal; lds_c[PC::kCam + 1] = A.plant.center; }
-    }
-
     double q[JG], dq[N], f_prev[R], des[R];                        // q: this lane's joints; dq: replicated command
     double sn[JG], cs[JG];                                         // sin / cos of this lane's joint angles, carried from step to step
     bool reseed = true;
@@ -918,6 +895,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
     bool alive = true, flagged = false;                          // flagged: a rank-deficient Jacobian was seen -> careful second pass
 #pragma unroll
     for (int r = 0; r < R; ++r) des[r] = own_row([&](int row) { return fp.desired[row]; }, r);
+    double restored_word = 0.0;
     // The state of a trial chunk between two of its segments, [field][lane] in the workspace (seg_state_doubles per lane).
     auto seg_state = [&](auto saving) {
         constexpr bool SAVE = decltype(saving)::value;
@@ -980,11 +958,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             const int bits = (alive ? 1 : 0) | (flagged ? 2 : 0) | (reseed ? 4 : 0) | (status << 8);
             double word = __hiloint2double(k_done, bits);
             io(word);
-            if constexpr (!SAVE) {
-                const int b = __double2loint(word);
-                alive = b & 1; flagged = b & 2; reseed = b & 4; status = b >> 8;
-                k_done = __double2hiint(word);
-            }
+            if constexpr (!SAVE) restored_word = word;                 // decoded by the caller, AFTER the rest of the prologue: consuming it here would wait out every load above
         }
     };
     await_predecessor();
@@ -1043,6 +1017,38 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     if (r < PV) p[r < PV ? r : 0][Sym<N>::at(l, j)] = v;
                     else if constexpr (!SHARED_P) lds_p[(r - PV) * NP + Sym<N>::at(l, j)][lane] = v;
                 }
+    }
+    // (round 6) The rest of the prologue runs UNDER the state restore: a later work item issues its 63 register loads and 39 LDS-direct requests
+    // first (5-6 us to arrive), then fills the plant constants and asks for its first noise rows; the flags word is decoded after that.
+    double nz_early[R];                                            // the first noise rows of the segment as planned (a fallback reloads those of step 0)
+    const int k_planned = k_begin;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nz_early[r] = 0.0;
+    if (on_noise && k_planned < K) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz_early[r] = (pn + (long long)k_planned * A.noise.sk)[r * RS * A.noise.sc];
+    }
+    if constexpr (DH) {
+        if (lane < N) {
+            lds_c[PC::kJoint + 5 * lane + 0] = A.plant.theta_offset[lane];
+            lds_c[PC::kJoint + 5 * lane + 1] = A.plant.d[lane];
+            lds_c[PC::kJoint + 5 * lane + 2] = A.plant.a[lane];
+            lds_c[PC::kJoint + 5 * lane + 3] = A.plant.cos_alpha[lane];
+            lds_c[PC::kJoint + 5 * lane + 4] = A.plant.sin_alpha[lane];
+        }
+        if (lane < M / 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lds_c[PC::kPoint + 3 * lane + c] = A.plant.points[lane][c];
+        }
+        if (lane == 0) { lds_c[PC::kCam] = A.plant.focal; lds_c[PC::kCam + 1] = A.plant.center; }
+    }
+
+    if constexpr (SEG) {
+        if (!fresh) {
+            const int b = __double2loint(restored_word);
+            alive = b & 1; flagged = b & 2; reseed = b & 4; status = b >> 8;
+            k_done = __double2hiint(restored_word);
+        }
     }
     __syncthreads();                                               // lds_c is read by every lane
 
