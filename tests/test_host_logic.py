@@ -420,3 +420,11 @@ def test_counter_figures_belong_to_this_library(uvs):
     assert tr.get('library_version') == version, ('profiles/traffic_latest.json was counted on other kernels: re-run tools/profile_round.sh + '
                                                   'tools/make_traffic_json.py', tr.get('library_version'), version)
     assert tr['kernel'].startswith('closed_loop_tuned_kernel<8,6,2,GMCKF') and tr['round'] >= 6
+
+
+def test_documents_stay_readable():
+    """No line of the Markdown documents over 160 characters (evidence legibility) -- `python tools/reflow_md.py <file>` re-wraps paragraphs and
+    turns a table with an over-long row into a list."""
+    for name in ('DESIGN.md', 'DESIGN_APPENDIX.md', 'README.md', 'INTEGRATION.md', os.path.join('profiles', 'README.md')):
+        longest = max(len(line) for line in open(os.path.join(ROOT, name), encoding='utf-8').read().split('\n'))
+        assert longest <= 160, (name, longest)

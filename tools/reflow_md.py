@@ -66,22 +66,35 @@ def reflow(lines):
                 out += rows
             i = j
             continue
-        if len(line) <= WIDTH or line.startswith('#') and len(line) <= WIDTH:
+        if line.startswith('#'):
+            if len(line) <= WIDTH:
+                out.append(line)
+            else:                                                # an over-long heading: keep its first part as the heading, the rest as text
+                head, _, rest = line.partition(' — ')
+                out.append(head)
+                if rest:
+                    out += [''] + wrap(rest, '', '')
+            i += 1
+            continue
+        if not line.strip():
             out.append(line)
             i += 1
             continue
+        # a paragraph or a list item with its continuation lines: re-wrapped as a whole when one of its lines runs long
         m = re.match(r'^(\s*)([-*+]|\d+\.)\s+', line)
-        if line.startswith('#'):                                 # an over-long heading: keep the first sentence as the heading, the rest as text
-            head, _, rest = line.partition(' — ')
-            out.append(head)
-            if rest:
-                out += [''] + wrap(rest, '', '')
+        j = i + 1
+        while j < n and lines[j].strip() and not lines[j].lstrip().startswith(('|', '#', '```')) and not re.match(r'^\s*([-*+]|\d+\.)\s+', lines[j]):
+            j += 1
+        block = lines[i:j]
+        if max(len(x) for x in block) <= WIDTH:
+            out += block
         elif m:
-            out += wrap(line[m.end():], m.group(0), ' ' * len(m.group(0)))
+            text = ' '.join([line[m.end():].strip()] + [x.strip() for x in block[1:]])
+            out += wrap(text, m.group(0), ' ' * len(m.group(0)))
         else:
             lead = re.match(r'^\s*', line).group(0)
-            out += wrap(line.strip(), lead, lead)
-        i += 1
+            out += wrap(' '.join(x.strip() for x in block), lead, lead)
+        i = j
     return out
 
 

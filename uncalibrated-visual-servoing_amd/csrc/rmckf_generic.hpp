@@ -256,7 +256,18 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs A) {
     }
     st.template update<METHOD_T>(fp, z, h, bandwidth(fp, A.k), kap);
     const int bad = st.any_nonfinite();
-    control_law<M, N, L, true>(st, kap, err, fp.gain, sub, cmd);   // one step, latency-bound: numpy's pinv semantics inline
+    // numpy's pinv semantics inline (there is no second pass behind a single step).  Round 5 ran the careful solve -- Householder QR finished by a Jacobi
+    // SVD of the factor -- on every call: 45 of the 59 us of a drop-in step were this one wavefront's SVD sweeps (tools/time_step_route.py).  Round 6: the
+    // plain QR with the default mode's watches first (spread of the factor's entries, growth of the solution), the careful solve only for a filter whose
+    // watch fires -- or for every filter under UVS_OPT_STRICT_PINV.  A filter's command never depends on its neighbours in the wavefront.
+    const bool strict = (fp.reserved & UVS_OPT_STRICT_PINV) != 0;
+    const bool suspect = strict || control_law<M, N, L, false>(st, kap, err, fp.gain, sub, cmd);
+    if (__any(suspect)) {
+        double careful[N];
+        control_law<M, N, L, true>(st, kap, err, fp.gain, sub, careful);
+#pragma unroll
+        for (int j = 0; j < N; ++j) cmd[j] = suspect ? careful[j] : cmd[j];
+    }
     if (!valid) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
