@@ -13,6 +13,10 @@ from conftest import GOLDEN
 
 SWEEPS = sorted(os.path.basename(p)[len('sweep_'):-4] for p in __import__('glob').glob(os.path.join(GOLDEN, 'sweep_*.npz')))
 K = 299
+# smallest fraction of trials that must be a parity statement (calm in the oracle, see below).  With the OUTLIER HOLD on (noise.py:103-116: a sample beyond
+# 20 is repeated for 10 steps) the closed loop amplifies rounding by ~1.16 x per step while an outlier is held: beyond the rho = 0 cell not even the oracle
+# reproduces the reference's trials (nor itself from a 1e-14-moved start) -- the experiment is then compared as a DISTRIBUTION: per-cell median ITAE within 5 %.
+MIN_CALM = {'r4_gmckf_mix_anneal_hold': 0.08}
 STATS_TOL = 1e-8          # stats <= 1e-9 is the oracle-vs-kernel gate on calm trials; 1e-8 is the verdict's bar against the reference
 MEDIAN_TOL = 1e-6
 
@@ -93,6 +97,12 @@ def check_against_reference(uvs, name, ref, plan, stats, status, k_done, who):
             for j in range(3):
                 assert abs(np.median(stats[ok, j]) - ref['cell_median'][c, j]) <= MEDIAN_TOL * ref['cell_median'][c, j]
                 assert abs(np.mean(stats[ok, j]) - ref['cell_mean'][c, j]) <= MEDIAN_TOL * ref['cell_mean'][c, j]
+    if name in MIN_CALM:                                         # chaotic experiment: the cells as distributions
+        for c in range(12):
+            mr, mm = np.median(ref['stats'][cell == c, 2]), np.median(stats[cell == c, 2])
+            assert abs(mm - mr) <= 0.05 * mr, (name, c, mr, mm)
+        assert calm[cell == 0].all()                             # rho = 0: no outlier, nothing held, every trial reproduced
+    assert calm.mean() >= MIN_CALM.get(name, 0.999 if name in ('r1_kf', 'r1_gmckf') else 0.95), (name, calm.mean())
     line = (f'sweep {name} ({who}): {T} trials of the reference main.py, FAIL ref {int(ref["status"].sum())} / here {int(status.sum())}, '
             f'calm {int(calm.sum())} ({calm.mean():.3f}), statistics on calm trials max {dev[calm].max():.1e}, FAIL per cell ref {fails_ref.tolist()}')
     print(line)

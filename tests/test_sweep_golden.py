@@ -1,5 +1,6 @@
-"""The reference's EXPERIMENT (main.py:104-196 at full length, reduced as results/plot_errorbar.m:20-98) against the C oracle: ten 1 200-trial
-sweeps of the unmodified reference -- results1 / results2 / results3 protocols, all four estimators -- committed as tests/golden/sweep_*.npz
+"""The reference's EXPERIMENT (main.py:104-196 at full length, reduced as results/plot_errorbar.m:20-98) against the C oracle: twelve 1 200-trial
+sweeps of the unmodified reference -- results1 / results2 / results3 protocols, all four estimators, and the Gaussian-mixture sweep of BASELINE config 3 with the
+outlier hold off and on -- committed as tests/golden/sweep_*.npz
 (oracle/gen_golden_sweep.py).  CPU test; tests/test_gpu_sweep.py holds batch.run_sweep to the same fixtures."""
 import numpy as np
 import pytest
@@ -7,8 +8,9 @@ import pytest
 from sweep_common import SWEEPS, check_against_reference, host_noise, load_sweep, oracle_kwargs
 
 
-def test_the_ten_reference_sweeps_are_committed():
-    assert SWEEPS == sorted(['r1_kf', 'r1_mckf', 'r1_imcckf', 'r1_gmckf', 'r2_kf', 'r2_mckf', 'r2_imcckf', 'r2_gmckf', 'r3_gmckf_anneal', 'r3_gmckf_sigma1'])
+def test_the_reference_sweeps_are_committed():
+    assert SWEEPS == sorted(['r1_kf', 'r1_mckf', 'r1_imcckf', 'r1_gmckf', 'r2_kf', 'r2_mckf', 'r2_imcckf', 'r2_gmckf', 'r3_gmckf_anneal', 'r3_gmckf_sigma1',
+                             'r4_gmckf_mix_anneal', 'r4_gmckf_mix_anneal_hold'])
     ref = load_sweep('r1_mckf')
     # the reference's own numbers: MCKF FAILs on its subnormal-weight path in the heavy-tailed cells only (INTEGRATION.md quotes this fixture)
     assert ref['cell_n_fail'].tolist() == [16, 5, 5, 1, 8, 4, 0, 0, 0, 0, 0, 0] and int(ref['status'].sum()) == 39
@@ -23,5 +25,4 @@ def test_c_oracle_reproduces_the_reference_experiment(name):
     cfg = ref['config']
     plan = uvs.batch.plan_trials(cfg)
     out = c_oracle.closed_loop_batch(plan.q_start, host_noise(uvs, cfg, plan), cfg['experiments']['desired_f'], **oracle_kwargs(cfg))
-    _, calm = check_against_reference(uvs, name, ref, plan, out['stats'], out['status'], out['k_done'], 'C oracle')
-    assert calm.mean() >= (0.999 if cfg['estimator']['method'] in ('KF', 'GMCKF') and name.startswith('r1') else 0.95)
+    check_against_reference(uvs, name, ref, plan, out['stats'], out['status'], out['k_done'], 'C oracle')
