@@ -342,46 +342,58 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4        # 256 CUs x 4 SIMDs, one wa
 FP64_VECTOR_PEAK_FLOPS = 78.6e12                     # MI355X_MICROARCH.md: fp64 vector peak
 
 
-def drop_in_step_latency(torch, uvs_amd, engine, dev, steps=400, warm=50):
+def drop_in_step_latency(torch, uvs_amd, engine, dev):  # noqa: C901
     """Latency of the drop-in STEP route (side object): what Experiment.run() pays per loop iteration for the estimator + control law when the
     robot is external (uncalibrated-visual-servoing_amd/experiment.py `_run_with_external_robot`, replacing experiment.py:166-312 of the
-    reference, which measured 260-430 us per update on the build container's CPU).  Host clock around
-    FilterBank.step_host -- numpy f / f_old in, numpy dq / err / status out, synchronised -- for T = 1 (the drop-in) and T = 64, and around the
-    round-5 route it replaces (three H2D tensors, launch, .item() + two .cpu() reads)."""
+    reference, which measured 260-430 us per update on the build container's CPU).  A real servo trial of BASELINE config 2
+    is driven from the host -- the package's host-side UR10 plant (plant.SyntheticRobot: kinematics and pinhole camera in numpy), the reference's
+    noise stream, the analytic initial guess, the command of every step fed back to the joints -- and the host clock runs around
+    FilterBank.step_host alone (numpy f / f_old in, numpy dq / err / status out, synchronised): T = 1 (the drop-in) and T = 64 copies of the trial,
+    and the same trial through the round-5 route (three H2D tensors, launch, .item() + two .cpu() reads)."""
     cfg = config2()
-    des = cfg['experiments']['desired_f']
+    ex = cfg['experiments']
+    des = np.asarray(ex['desired_f'], float)
     out = {}
-    rng = np.random.default_rng(7)
     for T in (1, 64):
-        fp = engine.make_params(8, 6, 'GMCKF', 10, False, 0.05, 15, 0.2, des, True, 0, 0)
-        x0 = rng.normal(size=(T, 48)) * 50
-        f = np.asarray(des)[None] + rng.normal(size=(T, 8))
         for route in ('host_io', 'tensors'):
-            bank = engine.FilterBank(fp, T, x0, dev)
+            robot = uvs_amd.SyntheticRobot(dt=ex['dt'])
+            robot.start(ex['q_start'])
+            prof = uvs_amd.NoiseProfiler(8, uvs_amd.NoiseType.ALPHA_STABLE, seed=cfg['noise']['seed'], noise_params=cfg['noise']['noise_params'])
+            f = np.asarray(robot.features(), float)
+            x0 = uvs_amd.Experiment._analytic_guess(robot, f, (256, 256), 8, 6)                # experiment.py:94-114
+            fp = engine.make_params(8, 6, 'GMCKF', 10, False, ex['dt'], ex['t_max'], ex['ibvs_gain'], des, True, 0, 0)
+            bank = engine.FilterBank(fp, T, np.tile(x0, (T, 1)), dev)
             dq = np.zeros((T, 6))
             lap = []
-            for k in range(warm + steps):
-                f_old, f = f, f + 0.1 * rng.normal(size=(T, 8))
+            for k in range(299):
+                f_old = f
+                f = np.asarray(robot.features(), float) + prof.getNoise()
+                fT, foT = np.tile(f, (T, 1)), np.tile(f_old, (T, 1))
                 t0 = time.perf_counter()
                 if route == 'host_io':
-                    dq_h, err_h, _, st = bank.step_host(f, f_old, k % 299, dq)
+                    dq_h, err_h, _, st = bank.step_host(fT, foT, k, dq)
                     bad = int(st[0])
                     dq = dq_h.copy()
                 else:
                     to = lambda a: torch.as_tensor(a, device=dev)          # noqa: E731
-                    dq_t, err_t, _, st = bank.step(to(f), to(f_old), to(dq), k % 299)
+                    dq_t, err_t, _, st = bank.step(to(fT), to(foT), to(dq), k)
                     bad = int(st[0].item())
                     dq = dq_t.cpu().numpy()
                     err_h = err_t.cpu().numpy()
                 lap.append(time.perf_counter() - t0)
                 assert bad == 0
-            lap = np.array(lap[warm:]) * 1e6
-            out[f'T{T}_{route}'] = {'median_us': float(np.median(lap)), 'mean_us': float(lap.mean()), 'p95_us': float(np.quantile(lap, 0.95))}
-    out['step_latency_us'] = {'T1': out['T1_host_io']['median_us'], 'T64': out['T64_host_io']['median_us']}
+                robot.setJointsPos(robot.getJointsPos() + dq[0] * ex['dt'])                  # experiment.py:320, 335
+                robot.step()
+            final_err = float(np.abs(np.asarray(robot.features()) - des).max())
+            lap = np.array(lap[20:]) * 1e6
+            out[f'T{T}_{route}'] = {'median_us': float(np.median(lap)), 'mean_us': float(lap.mean()), 'p95_us': float(np.quantile(lap, 0.95)),
+                                     'final_feature_error_px': final_err}
+    out = {'step_latency_us': {'T1': out['T1_host_io']['median_us'], 'T64': out['T64_host_io']['median_us']},
+           'tensor_route_us': {'T1': out['T1_tensors']['median_us'], 'T64': out['T64_tensors']['median_us']}, 'detail': out}
     out['reference_us_per_update'] = [260, 430]
-    out['note'] = ('host wall clock per Experiment-loop iteration of the estimator + control-law step, inputs and outputs as numpy arrays on the host; host_io = '
-                   'FilterBank.step_host (pinned zero-copy records, one launch + one stream synchronisation), tensors = the round-5 route; reference figure: '
-                   'BASELINE.md section 2 (numpy, build container)')
+    out['note'] = ('host wall clock per Experiment-loop iteration of the estimator + control-law step on a real config-2 servo trial driven from the host (numpy plant, '
+                   'reference noise stream), inputs and outputs as numpy arrays; host_io = FilterBank.step_host (pinned zero-copy records, one launch + one stream '
+                   'synchronisation), tensors = the round-5 route; reference figure: BASELINE.md section 2 (numpy, build container)')
     return out
 
 
@@ -490,7 +502,7 @@ def compact_line(line):
     leave it -- every `note` and the kernel / stream descriptions live in README.md "Reading the bench line" -- and nested numbers keep six
     significant digits.  Contract keys (top level, `config.workload`, `roofline`'s own fields, `cpu_baseline`) are untouched;
     UVS_BENCH_FULL_JSON=<path> writes the unabridged object."""
-    prose = ('note', 'binds', 'kernel', 'streams', 'inputs', 'source', 'launches_timed', 'noise_gen_workers', 'latency_option', 'h2d_inclusive_updates_per_s',
+    prose = ('note', 'binds', 'kernel', 'streams', 'inputs', 'source', 'detail', 'launches_timed', 'noise_gen_workers', 'latency_option', 'h2d_inclusive_updates_per_s',
              'launches_while_sampling', 'trials_per_gpu')
     derivable = ('updates_per_s', 'updates_per_launch', 'algorithmic_bytes_per_update', 'unit', 'peak', 'wall_ms', 'updates_total', 'wave_instr_per_s',
                  'fp64_peak_flops', 'per_process_updates_per_s', 'min_kernel_ms', 'layout', 'cells', 'trials_per_cell')

@@ -225,6 +225,10 @@ int uvs_rmckf_replay_f32(const uvs_filter_params *fp, int64_t T, uvs_view_f32 f,
  *   X [T][m*n] inout, P [T][m][n][n] inout, f [T][m], f_old [T][m], dq_prev [T][n] in
  *   first: 1 on the first iteration (H = 0, :183-184); k: loop index for annealing (:270)
  *   dq_out [T][n], err_out [T][m], kappa_out [T][m] out; status [T] int32 out (FAIL = non-finite X)
+ * numpy's pinv semantics inline (no second pass follows a single step): the plain least-squares solve with the default mode's watches, and the
+ * careful solve (QR finished by an SVD of the factor, numpy's cutoff) for a filter whose watch fires -- for every filter under UVS_OPT_STRICT_PINV.
+ * The per-call operands (f, f_old, dq_prev, dq_out, err_out, kappa_out, status) may live in pinned host memory mapped to the device: the kernel reads
+ * and writes them in place, which is how the package's drop-in route runs without a copy in either direction (engine.FilterBank.step_host).
  */
 int uvs_rmckf_step_f64(const uvs_filter_params *fp, int64_t T, double *X, double *P, const double *f,
                        const double *f_old, const double *dq_prev, int32_t first, int32_t k,
