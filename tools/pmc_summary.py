@@ -19,7 +19,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r['Kernel_Name']:
             grid = r.get('Grid_Size_X') or r.get('Grid_Size') or '?'
-            key = (r['Kernel_Name'].split('(')[0][-60:] + ' grid=' + str(grid), r['Counter_Name'])
+            key = (r['Kernel_Name'].split('(')[0][-100:] + ' grid=' + str(grid), r['Counter_Name'])
             if halves and halves in r['Kernel_Name']:
                 rows[key].append((int(r.get('Dispatch_Id') or r.get('Dispatch_ID') or 0), float(r['Counter_Value'])))
             else:
