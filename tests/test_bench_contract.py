@@ -93,3 +93,19 @@ def test_bench_line_contract():
     assert d['value'] > 0 and abs(d['value'] - 4096 * 299 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     assert 'power' in r and (r['power'] is None or (len(r['power']['sclk_mhz']) >= 1 and min(r['power']['package_watts']) > 0))
     assert d['replay']['estimator_only']['achieved'] > 0
+
+
+@pytest.mark.gpu
+def test_drop_in_step_route_latency():
+    """the drop-in step route -- what Experiment.run() pays per loop iteration with an external robot -- measured as bench.py reports it
+    (`drop_in`): a real config-2 servo trial driven from the host, zero-copy pinned records.  <= 80 us per step at T = 1 (measured: 23-25 us; the reference's
+    numpy takes 260-430 us per update, the round-5 tensor route ~100 us on the same trial), and the trial converges."""
+    import torch
+    import uvs_amd
+    from uvs_amd import engine
+    import bench
+    d = bench.drop_in_step_latency(torch, uvs_amd, engine, torch.device('cuda'))
+    print('drop-in step latency:', {k: round(v, 1) for k, v in d['step_latency_us'].items()}, 'us; tensor route', {k: round(v, 1) for k, v in d['tensor_route_us'].items()})
+    assert d['step_latency_us']['T1'] <= 80.0 and d['step_latency_us']['T64'] <= 80.0
+    assert d['step_latency_us']['T1'] < d['tensor_route_us']['T1']
+    assert all(v['final_feature_error_px'] < 10.0 for v in d['detail'].values())
