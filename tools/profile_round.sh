@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # which kernels these counts belong to: the library's version string carries the fingerprint of its kernel sources (csrc/src_hash.py)
 python3 -c "import sys; sys.path.insert(0, '$REPO'); import uvs_amd; print(uvs_amd.lib().uvs_version().decode())" > $OUT/library_version.txt
 # the un-profiled line first: a profiled run clocks 2-3 % lower (MI355X_MICROARCH.md, DVFS give-back)
-python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
+UVS_BENCH_FULL_JSON=$OUT/bench_full.json python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 echo "bench line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-power > $OUT/stats_bench.json 2> $OUT/stats_bench.err
 echo "kernel trace done"
