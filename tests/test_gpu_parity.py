@@ -481,6 +481,28 @@ def test_closed_loop_stress_plant_record_layout(uvs):
         assert np.array_equal(a['stats'].cpu().numpy(), b['stats'].cpu().numpy()) and not b['status'].cpu().numpy().any()
 
 
+@pytest.mark.parametrize('method', ['KF', 'IMCCKF'])
+def test_pair_stores_write_the_same_x_stream(uvs, method):
+    """Round 6: the (8,6) two-lane KF / IMCC-KF kernels write a trial-fastest X stream as 16-byte pairs of consecutive trials out of LDS (even T and row
+    pitch; profiles/r06/pair_stores_ab.txt).  Same values, other store instructions: the stream equals, bit for bit, the one written through a [trial][step]
+    [component] view (plain 8-byte stores) -- whole wavefronts, a ragged last wavefront (T = 70), a batch of one pair, and beyond one round of wavefronts."""
+    import bench
+    cfg = bench.config2()
+    des = cfg['experiments']['desired_f']
+    plant = uvs.SyntheticPlant.ur10(des).to_struct()
+    for T, K in ((2, 40), (70, 299), (4098, 120), (33000, 30)):
+        cfg['experiments']['epoch'] = T
+        plan = uvs.batch.plan_trials(cfg, cells=[1.5])
+        noise = uvs.batch.device_noise(cfg, plan, 0, T, K, 'cuda', share=False)
+        q0 = _cuda(plan.q_start)
+        fp = uvs.engine.make_params(8, 6, method, 10, False, 0.05, 15, 0.2, des, True, 2, K)
+        a = uvs.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'))                      # x: [step][component][trial] -> pair stores
+        b = uvs.engine.closed_loop(fp, plant, q0, noise, want=('x', 'err', 'q'), x_layout='tkc')      # x: [trial][step][component] -> 8-byte stores
+        assert np.array_equal(uvs.engine.as_tkc(a['x'], 'kct').cpu().numpy(), uvs.engine.as_tkc(b['x'], 'tkc').cpu().numpy()), (method, T)
+        for key in ('err', 'q', 'stats', 'status', 'k_done'):
+            assert np.array_equal(a[key].cpu().numpy(), b[key].cpu().numpy()), (method, T, key)
+
+
 # ---------------------------------------------------------------------------------------------- failure semantics
 def test_non_finite_state_fails_the_trial_only(uvs):
     g = load_golden('closed_gmckf_a1p5')

@@ -305,7 +305,7 @@ def test_default_kernels_have_no_scratch():
     for method in (2, 3, 4, 5):                                              # KF, MCKF, IMCCKF, GMCKF
         for plant in (0, 1, 2):                                              # DH, linear, DH with the UR10-like table's compile-time zeros
             for xout in ('true', 'false'):
-                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false, {"true" if method == 3 else "false"}, false, false>']
+                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false, {"true" if method == 3 else "false"}, false, false, false>']
                 # MCKF (round 5): its fixed-point branch -- rare, spread over the wavefront -- runs at the edge of the 512 registers and keeps a few spill
                 # slots (a handful of scratch accesses per firing of the branch, none on the plain step: tools/main_path.py); every other
                 # estimator carries no private segment at all
@@ -318,18 +318,22 @@ def test_default_kernels_have_no_scratch():
     for method in (2, 4, 5):
         for plant in (0, 2):
             for xout in ('true', 'false'):
-                assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, {plant}, 2, {xout}, true, false, false, false>']['scratch'] == 0
+                assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, {plant}, 2, {xout}, true, false, false, false, false>']['scratch'] == 0
         for xout in ('true', 'false'):
-            assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, 0, 2, {xout}, false, false, false, false>']['scratch'] == 0
+            assert k[f'closed_loop_tuned_kernel<8, 6, 4, {method}, 0, 2, {xout}, false, false, false, false, false>']['scratch'] == 0
     for plant in (0, 2):                                                     # RMCKF's segmented instantiation (launches that are not a whole number of rounds)
         for xout in ('true', 'false'):
-            assert k[f'closed_loop_tuned_kernel<8, 6, 2, 5, {plant}, 2, {xout}, false, true, false, false>']['scratch'] == 0
+            assert k[f'closed_loop_tuned_kernel<8, 6, 2, 5, {plant}, 2, {xout}, false, true, false, false, false>']['scratch'] == 0
     for plant in (0, 2):                                                     # the strict-mode instantiations (round 6: the certificate compiled in)
         for xout in ('true', 'false'):
-            assert k[f'closed_loop_tuned_kernel<8, 6, 2, 3, {plant}, 2, {xout}, false, true, false, true>']['scratch'] <= 128
+            assert k[f'closed_loop_tuned_kernel<8, 6, 2, 3, {plant}, 2, {xout}, false, true, false, true, false>']['scratch'] <= 128
             for method in (2, 4):
-                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false, false, false, true>']
+                r = k[f'closed_loop_tuned_kernel<8, 6, 2, {method}, {plant}, 2, {xout}, false, false, false, true, false>']
                 assert r['scratch'] <= 64 and r['vgpr'] <= 256, (method, plant, xout, r)
+    for plant in (0, 2):                                                     # the pair-store instantiations (round 6): KF clean, IMCC-KF a few cold bytes
+        assert k[f'closed_loop_tuned_kernel<8, 6, 2, 2, {plant}, 2, true, false, false, true, false, true>']['scratch'] == 0
+        r = k[f'closed_loop_tuned_kernel<8, 6, 2, 4, {plant}, 2, true, false, false, true, false, true>']
+        assert r['scratch'] <= 32 and r['vgpr'] <= 256, r
     for name in ('closed_loop_wide_kernel<32, 7, 8, 5, true, true, 1>', 'closed_loop_wide_kernel<32, 7, 8, 2, true, true, 1>', 'closed_loop_wide_kernel<8, 6, 8, 5, true, false, 0>',
                  'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 0>', 'replay_rows_kernel<8, 6, 4, 5, true, true, true, false, 2>'):
         assert k[name]['scratch'] == 0, (name, k[name])

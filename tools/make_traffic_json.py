@@ -65,7 +65,7 @@ def entry(sub, grid, alg_bytes, label):
 
 
 U2, U3, K = 65536 * 299, 262144 * 299, 299
-head = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false>', 131072, U2 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
+head = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false, false>', 131072, U2 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
 doc = {'round': rnd, 'workload': 'BASELINE config 2, 65536 trials x 299 updates, X+err+q logged, layout kct', 'source': d + '/pmc_summary.txt',
        'note': 'rocprofv3 --pmc passes with --kernel-trace only (tools/profile_round.sh), per-dispatch averages; FETCH_SIZE doubled per the gfx950 correction '
                '(MI355X_MICROARCH.md, HBM section: documented for 16 B/lane reads; these are 8 B/lane and the doubled figure lands on the algorithmic read bytes '
@@ -73,10 +73,12 @@ doc = {'round': rnd, 'workload': 'BASELINE config 2, 65536 trials x 299 updates,
 doc.update(head)
 ver = os.path.join(d, 'library_version.txt')                     # written on the GPU box by tools/profile_round.sh: the library the counters were taken on
 doc['library_version'] = open(ver).read().strip() if os.path.exists(ver) else None
-doc['config3'] = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false>', 524288, U3 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
+doc['config3'] = entry('tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false, false>', 524288, U3 * 560, 'closed_loop_tuned_kernel<8,6,2,GMCKF,DH(axis-aligned),2,true>')
 doc['config5'] = entry('closed_loop_wide_kernel<32, 7, 8, 5, true, true', 524288, U2 * 2360, 'closed_loop_wide_kernel<32,7,8,GMCKF,true,true>')
 # (MCKF since round 4: 8 work items per trial chunk, grid 2048 x 8 x 64 -- its hand-over traffic, 141 doubles per lane and segment edge out and back, is part of the counters)
-doc['other_estimators'] = {name: entry(f'tuned_kernel<8, 6, 2, {code}, 2, 2, true, false, false, false, false>', 131072, U2 * 560, f'closed_loop_tuned_kernel<8,6,2,{name},DH(axis-aligned),2,true>')
+# KF / IMCC-KF (round 6): a trial-fastest X stream leaves through the pair-store instantiation (XREC + XPAIR)
+doc['other_estimators'] = {name: entry(f'tuned_kernel<8, 6, 2, {code}, 2, 2, true, false, false, true, false, true>', 131072, U2 * 560,
+                                       f'closed_loop_tuned_kernel<8,6,2,{name},DH(axis-aligned),2,true,XREC,XPAIR> (16-byte pair stores)')
                            for name, code in (('KF', 2), ('IMCCKF', 4))}
 # MCKF: bench.py launches the same kernel for alpha = 1.5 and then as often for alpha = 1.0; tools/pmc_summary.py --halves keeps the two apart.  The kernel-trace
 # mean mixes them and is dropped here (the bench line holds both times).

@@ -27,7 +27,7 @@ done
 cd $REPO
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_all_dispatches.csv
 # headline kernel: 5 warm-up dispatches, then the 20 timed ones; what follows at the same grid belongs to the side objects (other estimators use other instantiations; the end-to-end sweep re-launches this one)
-python3 tools/trace_summary.py $OUT/stats --skip "closed_loop_tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false> grid=131072:5:20" closed_loop_wide_kernel:2 replay_tuned_kernel:1 replay_rows_kernel:1 replay_f32_kernel:1 > $OUT/kernel_trace_summary.csv
+python3 tools/trace_summary.py $OUT/stats --skip "closed_loop_tuned_kernel<8, 6, 2, 5, 2, 2, true, false, false, false, false, false> grid=131072:5:20" closed_loop_wide_kernel:2 replay_tuned_kernel:1 replay_rows_kernel:1 replay_f32_kernel:1 > $OUT/kernel_trace_summary.csv
 (for n in 1 2 3 4 5 6; do for k in closed_loop_tuned closed_loop_wide replay_tuned replay_rows replay_f32 noise_kernel; do python3 tools/pmc_summary.py --halves '8, 6, 2, 3, ' $OUT/pmc_$n $k; done; done) > $OUT/pmc_summary.txt
 cat $OUT/kernel_trace_summary.csv
 tail -c 1500 $OUT/bench_line.json

@@ -17,6 +17,7 @@ ap.add_argument('--lanes', type=int, default=0)
 ap.add_argument('--alpha', type=float, default=1.5)
 ap.add_argument('--x-layout', default=None, help="layout of the X stream alone ('ktc' = per-trial records)")
 ap.add_argument('--segments', type=int, default=0, help='segments per trial (bits 8-15 of fp.reserved): 0 = library choice, 1 = whole trials')
+ap.add_argument('--reserved', type=int, default=0, help='extra bits OR-ed into fp.reserved (experiment switches of diagnostic builds)')
 ap.add_argument('--strict', action='store_true', help='UVS_OPT_STRICT_PINV: every solve certified / through the careful kernels')
 args = ap.parse_args()
 T, dev = args.trials, torch.device('cuda')
@@ -32,7 +33,7 @@ if args.reps > 1000:
     open('gpurun_out/.probe_started', 'w').write('1')                # tools/power_probe.sh waits for this
 for meth in args.methods.split(','):
     fp = engine.make_params(8, 6, meth, 10, False, 0.05, 15, 0.2, cfg['experiments']['desired_f'], True, args.lanes)
-    fp.reserved = (args.segments << 8) | (1 if args.strict else 0)
+    fp.reserved = (args.segments << 8) | (1 if args.strict else 0) | args.reserved
     ms = []
     for i in range(2 + args.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -766,12 +766,14 @@ constexpr int kSharedOcc = 2;           // wavefronts per SIMD of the two-lane K
 // (same registers, same main path).  In the MCKF kernel even the untaken branch cost the plain step 21 instructions of register shuffling (+ 0.8 %,
 // profiles/r06/strict_certificate_ab.txt), and the KF / IMCC-KF kernels, held to 256 registers for two wavefronts per SIMD, spilled 12 bytes over
 // it: those three take it as a compile-time switch, and the launcher picks their CERT instantiations in strict mode.
+// XPAIR (round 6; with XREC): the X stream leaves LDS as 16-byte pairs of consecutive trials into TRIAL-FASTEST rows instead of as records (store_records).
 template <int M, int N, int L, int METHOD, int PLANT, int PV, bool XOUT, bool EMU2 = false, bool SEGMENTED = (METHOD == UVS_METHOD_MCKF), bool XREC = false,
-          bool CERT = false>
+          bool CERT = false, bool XPAIR = false>
 __global__ __launch_bounds__(64, (L >= 4 ? kL4Occ : ((METHOD == UVS_METHOD_KF || METHOD == UVS_METHOD_IMCCKF) && PV >= 1 && L == 2) ? kSharedOcc : 1))
 void closed_loop_tuned_kernel(const ClosedArgs A) {
     static_assert(M >= N && (L == 1 || L == 2 || L == 4) && M % L == 0, "tuned kernel: tall Jacobian, 1, 2 or 4 lanes per filter");
     static_assert(!XREC || (XOUT && L == 2 && !EMU2 && M == 8 && N == 6 && METHOD != UVS_METHOD_MCKF), "record stores: the (8,6) two-lane kernels with X in LDS (MCKF rewrites rows of a step)");
+    static_assert(!XPAIR || XREC, "pair stores are a flavour of the LDS store path");
     constexpr bool XREG = (L >= 4);                                // X in registers instead of LDS
     // MCKF trials differ in length (a trial that iterates costs its whole wavefront the fixed-point branch): with exactly two rounds of
     // wavefronts a slow one serialises with its slot's second wavefront.  The two-lane MCKF kernel can therefore run a chunk's K steps as
@@ -1118,6 +1120,35 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
             // writes pair 8 b + pp (two consecutive components, 16 bytes) of trial 8 a + tg -- eight trials x 128 contiguous bytes per instruction.
             // The pair sits in one row of X (N is even): LDS cell [r N + j][2 trial + s] and the one 64 doubles further.
             typedef double v2d __attribute__((ext_vector_type(2)));
+            if constexpr (XPAIR) {
+                // Trial-fastest rows ([step][component][trial], the package's default layout; round 6): the same idea for the OTHER layout.  A row of X in
+                // LDS is [lane] = [2 trial + s], so four consecutive doubles are (trial 2u row 2r, trial 2u row 2r + 1, trial 2u + 1 row 2r, trial 2u + 1
+                // row 2r + 1) of one column j: two 16-byte pairs of consecutive trials, for the components (2r, j) and (2r + 1, j).  Lane (r, u) = (lane / 16,
+                // lane % 16) takes local row r and trial pair u (skewed by 2 r so that the four rows read different LDS banks): per step 6 x (32 bytes out of
+                // LDS, two 16-byte stores), every store instruction four runs of 256 contiguous bytes -- 12 stores instead of 24 of 8 bytes.
+                const int r4 = (int)(lane >> 4), u = (int)((lane + 2u * (lane >> 4)) & 15u);
+                // two cursors walk the six columns of rows 2 r and 2 r + 1 (a component is x_out.sc doubles further): twelve precomputed row addresses would
+                // live across the whole step loop -- 24 registers this 256-register kernel does not have
+                double *pe = A.x_out.p + ((long long)k * A.x_out.sk + wave_first + 2 * u) + (long long)(2 * r4 * N) * A.x_out.sc;
+                double *po = pe + (long long)N * A.x_out.sc;
+                const bool live = wave_first + 2 * u < A.T;            // (T is even on this path: a pair is inside the batch or outside it)
+                const double *cell = &lds_x[r4 * N][4 * u];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const v2d lo = *reinterpret_cast<const v2d *>(cell + 64 * j), hi = *reinterpret_cast<const v2d *>(cell + 64 * j + 2);
+                    v2d even, odd;
+                    even.x = lo.x; even.y = hi.x;
+                    odd.x = lo.y; odd.y = hi.y;
+                    if (live) {
+                        *reinterpret_cast<v2d *>(pe) = even;
+                        *reinterpret_cast<v2d *>(po) = odd;
+                    }
+                    pe += A.x_out.sc;
+                    po += A.x_out.sc;
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);   // two columns (8 doubles) in flight at a time
+                }
+                return;
+            } else {
             const int tg = (int)(lane >> 3), pp8 = (int)(lane & 7u);
             double *rec = A.x_out.p + (long long)k * A.x_out.sk + wave_first * (long long)(M * N) + tg * (M * N);
             const double *xl = &lds_x[0][0] + 2 * tg;
@@ -1133,6 +1164,7 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                     v.y = xl[cell + 64 + 16 * a];
                     if (wave_first + 8 * a + tg < A.T) *reinterpret_cast<v2d *>(rec + (long long)(8 * a) * (M * N) + 2 * cp) = v;
                 }
+            }
             }
         }
     };
