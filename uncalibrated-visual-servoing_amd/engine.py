@@ -135,10 +135,11 @@ def launch_closed_loop(fp, plant_struct, T, *args, device=None):
 def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err', 'q'), layout='kct', final_state=False, x_layout=None, reuse=None):
     """Launch T closed-loop trials.  ``q_start``: (T, n) cuda tensor; ``noise``: stream tensor in ``layout`` or None;
     ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``).
-    ``x_layout``: another layout for the X stream alone.  'ktc' (per-trial records) is the faster store path of the (8,6) KF kernel on batches above
-    16 384 trials (two lanes per filter): 2.57 -> 2.26 ms on the headline workload (bench.py `other_estimators.KF.x_records`).  Only there: the IMCC-KF record
-    instantiation spills 60 B at its 256-register budget and is NOT faster (2.35 -> 2.54 ms; round 5 had measured - 0.7 %), RMCKF and MCKF keep their strided
-    stores whatever the view, and smaller batches run on the four-lane kernels, for which 'ktc' is an uncoalesced, slower path.
+    ``x_layout``: another layout for the X stream alone.  The default -- X trial-fastest like every stream -- is what the kernels are tuned for (since round 6
+    the (8,6) KF / IMCC-KF kernels write it as 16-byte pairs of consecutive trials when T is even).  'ktc' (per-trial records) is faster still for KF on
+    batches above 16 384 trials (two lanes per filter): 2.51 -> 2.28 ms on the headline workload (bench.py `other_estimators.KF.x_records`).  Only there: the
+    IMCC-KF record instantiation spills 60 B at its 256-register budget and is NOT faster (2.29 -> 2.54 ms), RMCKF and MCKF keep their strided stores whatever
+    the view, and smaller batches run on the four-lane kernels, for which 'ktc' is an uncoalesced, slower path.
     ``reuse``: the dict an earlier call with at least as many trials returned -- its tensors are written again ([..., :T] of the streams,
     [:T] of the per-trial arrays) instead of allocating new ones (batch.run_sweep: cell after cell through one set of buffers)."""
     x_layout = x_layout or layout
