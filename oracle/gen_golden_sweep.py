@@ -16,6 +16,7 @@ Jobs (``python oracle/gen_golden_sweep.py [job ...]``; none = all, four at a tim
   results2 protocol  the same with change_q_start (the shipped config.json), epoch 100:   r2_kf  r2_mckf  r2_imcckf  r2_gmckf
   results3 protocol  GMCKF: annealing / sigma = 1 (sigma = 10 is r1_gmckf), epoch 100:     r3_gmckf_anneal  r3_gmckf_sigma1
   mixture sweep      GAUSSIAN_MIXTURE rho = linspace(0, .2, 12), annealed sigma, hold off / on:  r4_gmckf_mix_anneal  r4_gmckf_mix_anneal_hold
+  other noise laws   GAUSSIAN_BIMODAL under IMCC-KF, WHITE_NOISE under KF:                     r5_imcckf_bimodal  r5_kf_white
 
 The noise seed schedule (seed0 + global trial index) and the jitter stream are main.py's own; nothing of the reference is patched except
 the simulator class, the detector binding and the clock of the plant (gen_golden_csv.py).
@@ -49,7 +50,11 @@ JOBS = {'r1_kf':           ('KF',     False,    False,     10,        100),
         # BASELINE config 3's noise at experiment level: GAUSSIAN_MIXTURE, rho = linspace(0, 0.2, 12) (main.py:104), std 1 / mean 50 (the reference ships no
         # defaults for them; the outliers must exceed the hold threshold of 20, noise.py:103), annealed sigma, outlier hold off / on (0.5 s = 10 steps)
         'r4_gmckf_mix_anneal':      ('GMCKF', True, True, 10, 100),
-        'r4_gmckf_mix_anneal_hold': ('GMCKF', True, True, 10, 100)}
+        'r4_gmckf_mix_anneal_hold': ('GMCKF', True, True, 10, 100),
+        # the remaining noise laws at experiment level (main.py sweeps rho for every type but ALPHA_STABLE; WHITE_NOISE ignores it: twelve cells that differ in
+        # their seeds only): the three-component bimodal mixture with its selector streams (noise.py:140-148) under IMCC-KF, white noise under KF
+        'r5_imcckf_bimodal': ('IMCCKF', True, False, 10, 100),
+        'r5_kf_white':       ('KF',     True, False, 10, 100)}
 
 
 def job_config(name):
@@ -62,6 +67,10 @@ def job_config(name):
     cfg['estimator']['estimator_params'].update(annealing=anneal, kernel_bw=bw)
     if name.startswith('r4_'):
         cfg['noise'].update(type='GAUSSIAN_MIXTURE', noise_params={'std': 1.0, 'mean': 50.0}, hold=name.endswith('_hold'), hold_time=0.5)
+    if name == 'r5_imcckf_bimodal':
+        cfg['noise'].update(type='GAUSSIAN_BIMODAL', noise_params={'std': 1.0, 'mean': 30.0}, hold=False, hold_time=0.5)
+    if name == 'r5_kf_white':
+        cfg['noise'].update(type='WHITE_NOISE', noise_params={'std': 2.0}, hold=False, hold_time=0.5)
     return cfg
 
 

@@ -1,4 +1,4 @@
-"""batch.run_sweep against the reference's EXPERIMENT: the twelve 1 200-trial Monte-Carlo tables the unmodified main.py produced in the build
+"""batch.run_sweep against the reference's EXPERIMENT: the fourteen 1 200-trial Monte-Carlo tables the unmodified main.py produced in the build
 container (tests/golden/sweep_*.npz, oracle/gen_golden_sweep.py; main.py:104-196 reduced as results/plot_errorbar.m:20-98).  The sweep runs as
 the product runs it -- config.json in, device seeding + device noise + closed-loop kernels, per-trial rows out -- and every trial the oracle
 reproduces from a 1e-14-moved start must agree with the reference: status and k_done exact, ||ISE|| / ||IAE|| / ||ITAE|| to 1e-8, FAIL counts

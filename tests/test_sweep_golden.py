@@ -1,6 +1,6 @@
-"""The reference's EXPERIMENT (main.py:104-196 at full length, reduced as results/plot_errorbar.m:20-98) against the C oracle: twelve 1 200-trial
+"""The reference's EXPERIMENT (main.py:104-196 at full length, reduced as results/plot_errorbar.m:20-98) against the C oracle: fourteen 1 200-trial
 sweeps of the unmodified reference -- results1 / results2 / results3 protocols, all four estimators, and the Gaussian-mixture sweep of BASELINE config 3 with the
-outlier hold off and on -- committed as tests/golden/sweep_*.npz
+outlier hold off and on, the bimodal mixture under IMCC-KF and white noise under KF -- committed as tests/golden/sweep_*.npz
 (oracle/gen_golden_sweep.py).  CPU test; tests/test_gpu_sweep.py holds batch.run_sweep to the same fixtures."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ from sweep_common import SWEEPS, check_against_reference, host_noise, load_sweep
 
 def test_the_reference_sweeps_are_committed():
     assert SWEEPS == sorted(['r1_kf', 'r1_mckf', 'r1_imcckf', 'r1_gmckf', 'r2_kf', 'r2_mckf', 'r2_imcckf', 'r2_gmckf', 'r3_gmckf_anneal', 'r3_gmckf_sigma1',
-                             'r4_gmckf_mix_anneal', 'r4_gmckf_mix_anneal_hold'])
+                             'r4_gmckf_mix_anneal', 'r4_gmckf_mix_anneal_hold', 'r5_imcckf_bimodal', 'r5_kf_white'])
     ref = load_sweep('r1_mckf')
     # the reference's own numbers: MCKF FAILs on its subnormal-weight path in the heavy-tailed cells only (INTEGRATION.md quotes this fixture)
     assert ref['cell_n_fail'].tolist() == [16, 5, 5, 1, 8, 4, 0, 0, 0, 0, 0, 0] and int(ref['status'].sum()) == 39
