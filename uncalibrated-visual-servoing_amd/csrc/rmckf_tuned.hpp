@@ -1149,7 +1149,12 @@ void closed_loop_tuned_kernel(const ClosedArgs A) {
                 }
                 return;
             } else {
-            const int tg = (int)(lane >> 3), pp8 = (int)(lane & 7u);
+            unsigned ln = lane;
+            // IMCC-KF sits at its 256-register budget: with the lane-dependent cell / pair offsets below kept across the whole step loop its record instantiation
+            // spilled 60 B and ran 8 % slower than this; opaque, they are re-formed every step (a dozen integer instructions).  KF has the registers and keeps them
+            // (the same trick costs it 2 %): profiles/r06/pair_stores_ab.txt.
+            if constexpr (METHOD == UVS_METHOD_IMCCKF) asm volatile("" : "+v"(ln));
+            const int tg = (int)(ln >> 3), pp8 = (int)(ln & 7u);
             double *rec = A.x_out.p + (long long)k * A.x_out.sk + wave_first * (long long)(M * N) + tg * (M * N);
             const double *xl = &lds_x[0][0] + 2 * tg;
 #pragma unroll

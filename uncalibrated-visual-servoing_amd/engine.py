@@ -137,9 +137,9 @@ def closed_loop(fp, plant_struct, q_start, noise=None, x0=None, want=('x', 'err'
     ``x0``: (T, m*n) cuda tensor when fp.initial_guess == 0.  Returns a dict of output tensors (streams in ``layout``).
     ``x_layout``: another layout for the X stream alone.  The default -- X trial-fastest like every stream -- is what the kernels are tuned for (since round 6
     the (8,6) KF / IMCC-KF kernels write it as 16-byte pairs of consecutive trials when T is even).  'ktc' (per-trial records) is faster still for KF on
-    batches above 16 384 trials (two lanes per filter): 2.51 -> 2.28 ms on the headline workload (bench.py `other_estimators.KF.x_records`).  Only there: the
-    IMCC-KF record instantiation spills 60 B at its 256-register budget and is NOT faster (2.29 -> 2.54 ms), RMCKF and MCKF keep their strided stores whatever
-    the view, and smaller batches run on the four-lane kernels, for which 'ktc' is an uncoalesced, slower path.
+    batches above 16 384 trials (two lanes per filter; bench.py `other_estimators.KF.x_records`: up to - 10 %, box-dependent) and level with the default for
+    IMCC-KF.  Only there: RMCKF and MCKF keep their strided stores whatever the view, and smaller batches run on the four-lane kernels, for which 'ktc' is an
+    uncoalesced, slower path.
     ``reuse``: the dict an earlier call with at least as many trials returned -- its tensors are written again ([..., :T] of the streams,
     [:T] of the per-trial arrays) instead of allocating new ones (batch.run_sweep: cell after cell through one set of buffers)."""
     x_layout = x_layout or layout
